@@ -1,0 +1,158 @@
+"""Headline benchmark: fp64 CCSD-style contraction C[a,b,i,j] = sum_em A[a,e,i,m] * B[e,b,m,j]
+(BASELINE.json configs[1]) on MI355X through the C ABI of libctc_tc.so.
+
+  python bench.py --gpus N --steps K --warmup W [--extent 96]
+
+A step is one whole contraction with operands already resident in HBM.  With
+N > 1 (one process per GPU under torch.distributed.run) the contraction grows
+along the free index `a` (extent = N * extent): every rank owns one slab of A
+and of C, B is replicated, no collective touches the data path ("weak" scaling).
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import ctc_amd  # noqa: E402
+
+SPEC = "aeim,ebmj->abij"
+SEED_A, SEED_B = 0xC7C0A, 0xC7C0B
+# fp64 matrix peak of MI355X, dense, public datasheet value (256 CUs x 4 SIMDs x
+# 32 flop/clk x 2.4 GHz); the measured microarchitecture guide lists no fp64 row.
+PEAK_FP64_MFMA_TFLOPS = 78.6
+
+
+def cpu_baseline(extent, threads):
+    """The CPU oracle on the same contraction at a bounded extent (a few seconds of work)."""
+    from oracle import ref
+    import numpy as np
+    n = extent
+    ext = dict(a=n, b=n, i=n, j=n, e=n, m=n)
+    A = ref.fill(n ** 4, SEED_A)
+    B = ref.fill(n ** 4, SEED_B)
+    ref.contract(SPEC, dict(a=4, b=4, i=4, j=4, e=4, m=4), A, B, threads=threads)  # spin up the thread pool
+    t0 = time.perf_counter()
+    C = ref.contract(SPEC, ext, A, B, threads=threads)
+    dt = time.perf_counter() - t0
+    return 2.0 * n ** 6 / dt * 1e-12, dt, float(np.abs(C).max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--extent", type=int, default=96, help="extent of every mode (64..96 in BASELINE)")
+    ap.add_argument("--cpu-extent", type=int, default=56, help="extent of the CPU-oracle sample")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run" % (args.gpus, world))
+
+    n = args.extent
+    full_ext = dict(a=n * world, b=n, i=n, j=n, e=n, m=n)
+    full = ctc_amd.Plan(SPEC, full_ext, "f64")
+    plan, off_a, off_b, off_c = full.shard("a", rank, world)
+    # each rank holds only its slab of A and C; B is replicated
+    slab_a = n * n * n * n
+    A = torch.empty(slab_a, dtype=torch.float64, device=dev)
+    B = torch.empty(n ** 4, dtype=torch.float64, device=dev)
+    C = torch.empty(slab_a, dtype=torch.float64, device=dev)
+    ctc_amd.fill(A, SEED_A, first=off_a)
+    ctc_amd.fill(B, SEED_B)
+    plan.prepare()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.execute(A, B, C)
+    barrier()
+    t0 = time.perf_counter()
+    # K launches on torch's current stream, bracketed by HIP events on that same stream
+    kernel_ms = plan.time(A, B, C, warmup=0, iters=args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    flops_rank = plan.flops
+    flops_job = flops_rank * world
+    ms_per_step = elapsed / args.steps * 1e3
+    value = flops_job / (elapsed / args.steps) * 1e-12
+
+    if rank == 0:
+        s = plan.summary()
+        achieved = flops_rank / (kernel_ms * 1e-3) * 1e-12
+        out = {
+            "metric": "achieved TFLOP/s per contraction (fp64, C[a,b,i,j]=A[a,e,i,m]*B[e,b,m,j])",
+            "value": round(value, 3),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic (splitmix64 uniform[-1,1), generated in HBM)",
+            "config": {
+                "workload": "BASELINE configs[1]: abij=aeim,ebmj fp64, all extents %d%s" % (
+                    n, "" if world == 1 else ", free index a sharded: extent %d over %d GPUs" % (n * world, world)),
+                "gemm_view": {"M": s["M"], "N": s["N"], "K": s["K"]},
+                "tile": list(s["tile"]), "layout_a": s["layout_a"], "layout_b": s["layout_b"],
+                "flops_per_step": flops_job,
+                "pct_of_fp64_mfma_peak": round(100.0 * value / (PEAK_FP64_MFMA_TFLOPS * world), 2),
+            },
+            "roofline": {
+                "bound": "mfma",
+                "achieved": round(achieved, 3),
+                "peak": PEAK_FP64_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
+                "traffic": None,
+                "kernel": "gemm_kernel<double>",
+                "kernel_ms": round(kernel_ms, 4),
+                "algorithmic_flops_per_launch": flops_rank,
+            },
+        }
+        if not args.no_cpu and world == 1:
+            threads = min(16, os.cpu_count() or 1)
+            tf, dt, _ = cpu_baseline(args.cpu_extent, threads)
+            out["cpu_baseline"] = {
+                "value": round(tf, 5), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+                "sample": "same contraction at all extents %d (2*%d^6 flops, %.1f s) on the build's own CPU "
+                          "oracle; the reference has no CPU contraction path" % (args.cpu_extent, args.cpu_extent, dt),
+            }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,459 @@
+// C ABI of libctc_tc.so (declared in include/ctc_tc.h): thin host layer between
+// plain-C callers and the HIP kernels.  No torch types, no CUDA shims.
+#include "ctc_tc.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "permute_plan.hpp"
+#include "planner.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what)
+{
+    return fail(CTC_TC_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// offset tables of one plan resident on one device
+struct DeviceTables {
+    int64_t *base = nullptr;
+    const int64_t *row_a = nullptr, *k_a = nullptr, *k_b = nullptr, *col_b = nullptr;
+    const int64_t *row_c = nullptr, *col_c = nullptr, *bat_a = nullptr, *bat_b = nullptr, *bat_c = nullptr;
+};
+
+struct PermuteTables {
+    int64_t *base = nullptr;
+    ctc::PermuteParams params;
+};
+
+}  // namespace
+
+struct ctc_tc_plan {
+    ctc::Plan plan;
+    std::mutex mu;
+    std::map<int, DeviceTables> tables;  // by device ordinal
+    std::unique_ptr<ctc_tc_plan> packed;  // GEMM on packed [batch,M,K] x [batch,K,N] operands (TTGT)
+};
+
+namespace {
+
+int upload_tables(ctc_tc_plan *pl, int device, DeviceTables &out)
+{
+    std::lock_guard<std::mutex> lock(pl->mu);
+    auto it = pl->tables.find(device);
+    if (it != pl->tables.end()) {
+        out = it->second;
+        return CTC_TC_OK;
+    }
+    const ctc::Plan &p = pl->plan;
+    const std::vector<int64_t> *src[9] = {&p.row_a, &p.k_a, &p.k_b, &p.col_b, &p.row_c,
+                                          &p.col_c, &p.bat_a, &p.bat_b, &p.bat_c};
+    size_t total = 0;
+    size_t start[9];
+    for (int i = 0; i < 9; ++i) {
+        start[i] = total;
+        total += (src[i]->size() + 1) & ~size_t(1);  // keep every table 16-byte aligned
+    }
+    std::vector<int64_t> host(total, 0);
+    for (int i = 0; i < 9; ++i) std::copy(src[i]->begin(), src[i]->end(), host.begin() + start[i]);
+    DeviceTables t;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&t.base), total * sizeof(int64_t));
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(offset tables)");
+    e = hipMemcpy(t.base, host.data(), total * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(t.base);
+        return fail_hip(e, "hipMemcpy(offset tables)");
+    }
+    t.row_a = t.base + start[0];
+    t.k_a = t.base + start[1];
+    t.k_b = t.base + start[2];
+    t.col_b = t.base + start[3];
+    t.row_c = t.base + start[4];
+    t.col_c = t.base + start[5];
+    t.bat_a = t.base + start[6];
+    t.bat_b = t.base + start[7];
+    t.bat_c = t.base + start[8];
+    pl->tables[device] = t;
+    out = t;
+    return CTC_TC_OK;
+}
+
+std::mutex g_perm_mu;
+std::map<std::string, PermuteTables> g_perm_cache;  // key: device|elem|extents|perm
+
+int get_permute_tables(int device, int rank, const int64_t *extents, const int *perm, PermuteTables &out)
+{
+    std::string key = std::to_string(device) + "|";
+    for (int i = 0; i < rank; ++i) key += std::to_string(extents[i]) + ",";
+    key += "|";
+    for (int i = 0; i < rank; ++i) key += std::to_string(perm[i]) + ",";
+    std::lock_guard<std::mutex> lock(g_perm_mu);
+    auto it = g_perm_cache.find(key);
+    if (it != g_perm_cache.end()) {
+        out = it->second;
+        return CTC_TC_OK;
+    }
+    ctc::PermutePlan pp;
+    std::string e = ctc::plan_permute(rank, extents, perm, pp);
+    if (!e.empty()) return fail(CTC_TC_EINVAL, e);
+    const std::vector<int64_t> *src[6] = {&pp.in_x, &pp.out_x, &pp.in_y, &pp.out_y, &pp.in_o, &pp.out_o};
+    size_t total = 0, start[6];
+    for (int i = 0; i < 6; ++i) {
+        start[i] = total;
+        total += (src[i]->size() + 1) & ~size_t(1);
+    }
+    std::vector<int64_t> host(total, 0);
+    for (int i = 0; i < 6; ++i) std::copy(src[i]->begin(), src[i]->end(), host.begin() + start[i]);
+    PermuteTables t;
+    hipError_t he = hipMalloc(reinterpret_cast<void **>(&t.base), total * sizeof(int64_t));
+    if (he != hipSuccess) return fail_hip(he, "hipMalloc(permute tables)");
+    he = hipMemcpy(t.base, host.data(), total * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (he != hipSuccess) {
+        (void)hipFree(t.base);
+        return fail_hip(he, "hipMemcpy(permute tables)");
+    }
+    t.params.in_x = t.base + start[0];
+    t.params.out_x = t.base + start[1];
+    t.params.in_y = t.base + start[2];
+    t.params.out_y = t.base + start[3];
+    t.params.in_o = t.base + start[4];
+    t.params.out_o = t.base + start[5];
+    t.params.X = pp.X;
+    t.params.Y = pp.Y;
+    t.params.O = pp.O;
+    t.params.same_fast = pp.same_fast ? 1 : 0;
+    g_perm_cache[key] = t;
+    out = t;
+    return CTC_TC_OK;
+}
+
+int current_device(int &device)
+{
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return fail_hip(e, "hipGetDevice (is a gfx950 GPU visible?)");
+    return CTC_TC_OK;
+}
+
+template <typename V> int64_t copy_out(const V &v, int64_t *out, int64_t cap)
+{
+    const int64_t n = (int64_t)v.size();
+    if (out)
+        for (int64_t i = 0; i < n && i < cap; ++i) out[i] = (int64_t)v[(size_t)i];
+    return n;
+}
+
+int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, double beta, void *C,
+                hipStream_t stream)
+{
+    const ctc::Plan &p = pl->plan;
+    if (p.dtype == ctc::kBF16) return fail(CTC_TC_EUNSUPPORTED, "bf16 contractions are not implemented yet");
+    int device = 0;
+    int rc = current_device(device);
+    if (rc) return rc;
+    DeviceTables t;
+    rc = upload_tables(pl, device, t);
+    if (rc) return rc;
+
+    ctc::GemmParams g;
+    g.A = p.swapped ? B : A;
+    g.B = p.swapped ? A : B;
+    g.C = C;
+    g.row_a = t.row_a; g.k_a = t.k_a; g.k_b = t.k_b; g.col_b = t.col_b;
+    g.row_c = t.row_c; g.col_c = t.col_c;
+    g.bat_a = t.bat_a; g.bat_b = t.bat_b; g.bat_c = t.bat_c;
+    g.M = p.M; g.N = p.N; g.K = p.K;
+    g.batch = (int)p.batch;
+    g.alpha = alpha; g.beta = beta;
+    g.group = p.tile.group;
+    if (p.batch > 65535) return fail(CTC_TC_EUNSUPPORTED, "more than 65535 batch entries");
+
+    // vector loads need 16-byte aligned bases; otherwise fall back to element loads
+    int la = p.layout_a, lb = p.layout_b;
+    if (la != ctc::kLayoutScalar && (reinterpret_cast<uintptr_t>(g.A) & 15)) la = ctc::kLayoutScalar;
+    if (lb != ctc::kLayoutScalar && (reinterpret_cast<uintptr_t>(g.B) & 15)) lb = ctc::kLayoutScalar;
+
+    hipError_t e = ctc::launch_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, stream);
+    if (e != hipSuccess) return fail_hip(e, "contraction kernel launch");
+    return CTC_TC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctc_tc_version(void) { return 100; }
+
+const char *ctc_tc_last_error(void) { return g_last_error.c_str(); }
+
+int ctc_tc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ctc_tc_plan_create(const char *spec, int n_ext, const char *mode_names, const int64_t *extents,
+                       const int64_t *strides_a, const int64_t *strides_b, const int64_t *strides_c,
+                       int dtype, ctc_tc_plan **plan)
+{
+    if (!spec || !plan || n_ext < 0 || (n_ext > 0 && (!mode_names || !extents)))
+        return fail(CTC_TC_EINVAL, "null argument");
+    std::unique_ptr<ctc_tc_plan> pl(new ctc_tc_plan());
+    std::string e = ctc::build_plan(spec, n_ext, mode_names, extents, strides_a, strides_b, strides_c,
+                                    dtype, pl->plan);
+    if (!e.empty()) return fail(e.find("spec") != std::string::npos || e.find("mode") != std::string::npos
+                                    ? CTC_TC_ESPEC : CTC_TC_EINVAL, e);
+    *plan = pl.release();
+    return CTC_TC_OK;
+}
+
+int ctc_tc_plan_destroy(ctc_tc_plan *plan)
+{
+    if (!plan) return CTC_TC_OK;
+    for (auto &kv : plan->tables)
+        if (kv.second.base) (void)hipFree(kv.second.base);
+    if (plan->packed)
+        for (auto &kv : plan->packed->tables)
+            if (kv.second.base) (void)hipFree(kv.second.base);
+    delete plan;
+    return CTC_TC_OK;
+}
+
+int ctc_tc_plan_describe(const ctc_tc_plan *plan, char *buf, size_t buflen)
+{
+    if (!plan) return fail(CTC_TC_EINVAL, "null plan");
+    std::string s = ctc::describe(plan->plan);
+    if (buf && buflen) {
+        size_t n = s.size() < buflen - 1 ? s.size() : buflen - 1;
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return (int)s.size();
+}
+
+int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_t cap)
+{
+    if (!plan) return fail(CTC_TC_EINVAL, "null plan");
+    const ctc::Plan &p = plan->plan;
+    std::vector<int64_t> v;
+    switch (query) {
+    case CTC_TC_Q_NAMES: for (auto &m : p.modes) v.push_back((int64_t)m.name); break;
+    case CTC_TC_Q_CLASSES: for (auto &m : p.modes) v.push_back(m.cls); break;
+    case CTC_TC_Q_EXTENTS: for (auto &m : p.modes) v.push_back(m.extent); break;
+    case CTC_TC_Q_CANON_BATCH: return copy_out(p.canon_batch, out, cap);
+    case CTC_TC_Q_CANON_M: return copy_out(p.canon_m, out, cap);
+    case CTC_TC_Q_CANON_N: return copy_out(p.canon_n, out, cap);
+    case CTC_TC_Q_CANON_K: return copy_out(p.canon_k, out, cap);
+    case CTC_TC_Q_PERM_A: return copy_out(p.perm_a, out, cap);
+    case CTC_TC_Q_PERM_B: return copy_out(p.perm_b, out, cap);
+    case CTC_TC_Q_PERM_C: return copy_out(p.perm_c, out, cap);
+    case CTC_TC_Q_SWAPPED: v.push_back(p.swapped ? 1 : 0); break;
+    case CTC_TC_Q_EXEC_BATCH: return copy_out(p.ex_batch, out, cap);
+    case CTC_TC_Q_EXEC_M: return copy_out(p.ex_m, out, cap);
+    case CTC_TC_Q_EXEC_N: return copy_out(p.ex_n, out, cap);
+    case CTC_TC_Q_EXEC_K: return copy_out(p.ex_k, out, cap);
+    case CTC_TC_Q_GEMM_DIMS: v = {p.M, p.N, p.K, p.batch}; break;
+    case CTC_TC_Q_TILE:
+        v = {p.tile.bm, p.tile.bn, p.tile.bk, p.tile.threads, p.layout_a, p.layout_b,
+             p.vec_a, p.vec_b, p.tile.group};
+        break;
+    case CTC_TC_Q_ROW_A: return copy_out(p.row_a, out, cap);
+    case CTC_TC_Q_K_A: return copy_out(p.k_a, out, cap);
+    case CTC_TC_Q_K_B: return copy_out(p.k_b, out, cap);
+    case CTC_TC_Q_COL_B: return copy_out(p.col_b, out, cap);
+    case CTC_TC_Q_ROW_C: return copy_out(p.row_c, out, cap);
+    case CTC_TC_Q_COL_C: return copy_out(p.col_c, out, cap);
+    case CTC_TC_Q_BAT_A: return copy_out(p.bat_a, out, cap);
+    case CTC_TC_Q_BAT_B: return copy_out(p.bat_b, out, cap);
+    case CTC_TC_Q_BAT_C: return copy_out(p.bat_c, out, cap);
+    case CTC_TC_Q_FLOPS: v.push_back(2 * p.M * p.N * p.K * p.batch); break;
+    default: return fail(CTC_TC_EINVAL, "unknown query");
+    }
+    return copy_out(v, out, cap);
+}
+
+int ctc_tc_plan_shard(const ctc_tc_plan *plan, char mode, int rank, int nranks, ctc_tc_plan **shard,
+                      int64_t *off_a, int64_t *off_b, int64_t *off_c)
+{
+    if (!plan || !shard) return fail(CTC_TC_EINVAL, "null argument");
+    std::unique_ptr<ctc_tc_plan> pl(new ctc_tc_plan());
+    int64_t oa = 0, ob = 0, oc = 0;
+    std::string e = ctc::shard_plan(plan->plan, mode, rank, nranks, pl->plan, oa, ob, oc);
+    if (!e.empty()) return fail(CTC_TC_EINVAL, e);
+    if (off_a) *off_a = oa;
+    if (off_b) *off_b = ob;
+    if (off_c) *off_c = oc;
+    *shard = pl.release();
+    return CTC_TC_OK;
+}
+
+int ctc_tc_plan_prepare(ctc_tc_plan *plan)
+{
+    if (!plan) return fail(CTC_TC_EINVAL, "null plan");
+    int device = 0;
+    int rc = current_device(device);
+    if (rc) return rc;
+    DeviceTables t;
+    return upload_tables(plan, device, t);
+}
+
+int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta, void *C,
+                   void *stream)
+{
+    if (!plan || !A || !B || !C) return fail(CTC_TC_EINVAL, "null argument");
+    return launch_plan(plan, alpha, A, B, beta, C, static_cast<hipStream_t>(stream));
+}
+
+int ctc_tc_permute(const void *in, void *out, int rank, const int64_t *extents_in, const int *perm,
+                   int elem_size, void *stream)
+{
+    if (!in || !out || !extents_in || !perm) return fail(CTC_TC_EINVAL, "null argument");
+    if (in == out) return fail(CTC_TC_EINVAL, "in-place permutation is not supported");
+    int device = 0;
+    int rc = current_device(device);
+    if (rc) return rc;
+    PermuteTables t;
+    rc = get_permute_tables(device, rank, extents_in, perm, t);
+    if (rc) return rc;
+    ctc::PermuteParams p = t.params;
+    p.in = in;
+    p.out = out;
+    hipError_t e = ctc::launch_permute(elem_size, p, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "permute kernel launch");
+    return CTC_TC_OK;
+}
+
+int64_t ctc_tc_ttgt_workspace_bytes(const ctc_tc_plan *plan)
+{
+    if (!plan) return fail(CTC_TC_EINVAL, "null plan");
+    const ctc::Plan &p = plan->plan;
+    const int64_t es = ctc::dtype_size(p.dtype);
+    auto pad = [](int64_t b) { return (b + 255) & ~int64_t(255); };
+    return pad(p.size_a * es) + pad(p.size_b * es) + pad(p.size_c * es);
+}
+
+int ctc_tc_execute_ttgt(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta,
+                        void *C, void *workspace, int64_t workspace_bytes, void *stream)
+{
+    if (!plan || !A || !B || !C || !workspace) return fail(CTC_TC_EINVAL, "null argument");
+    if (beta != 0.0) return fail(CTC_TC_EUNSUPPORTED, "the explicit-transpose path supports beta == 0 only");
+    const ctc::Plan &p = plan->plan;
+    for (size_t i = 0; i < p.strides_a.size(); ++i) {
+        // the explicit transposes assume packed operands
+        int64_t s = 1;
+        for (size_t j = i + 1; j < p.a_modes.size(); ++j) s *= p.modes[p.a_modes[j]].extent;
+        if (p.strides_a[i] != s) return fail(CTC_TC_EUNSUPPORTED, "explicit-transpose path needs packed operands");
+    }
+    for (size_t i = 0; i < p.strides_b.size(); ++i) {
+        int64_t s = 1;
+        for (size_t j = i + 1; j < p.b_modes.size(); ++j) s *= p.modes[p.b_modes[j]].extent;
+        if (p.strides_b[i] != s) return fail(CTC_TC_EUNSUPPORTED, "explicit-transpose path needs packed operands");
+    }
+    for (size_t i = 0; i < p.strides_c.size(); ++i) {
+        int64_t s = 1;
+        for (size_t j = i + 1; j < p.c_modes.size(); ++j) s *= p.modes[p.c_modes[j]].extent;
+        if (p.strides_c[i] != s) return fail(CTC_TC_EUNSUPPORTED, "explicit-transpose path needs packed operands");
+    }
+    if (workspace_bytes < ctc_tc_ttgt_workspace_bytes(plan)) return fail(CTC_TC_EINVAL, "workspace too small");
+    const int es = ctc::dtype_size(p.dtype);
+    auto pad = [](int64_t b) { return (b + 255) & ~int64_t(255); };
+    char *wa = static_cast<char *>(workspace);
+    char *wb = wa + pad(p.size_a * es);
+    char *wc = wb + pad(p.size_b * es);
+
+    {
+        std::lock_guard<std::mutex> lock(plan->mu);
+        if (!plan->packed) {
+            // same contraction on operands already in [batch,M,K] / [batch,K,N] / [batch,M,N] order
+            std::string sa, sb, sc, names;
+            std::vector<int64_t> ext;
+            auto add = [&](std::string &s, const std::vector<int> &ids) {
+                for (int id : ids) s.push_back(p.modes[id].name);
+            };
+            add(sa, p.canon_batch); add(sa, p.canon_m); add(sa, p.canon_k);
+            add(sb, p.canon_batch); add(sb, p.canon_k); add(sb, p.canon_n);
+            add(sc, p.canon_batch); add(sc, p.canon_m); add(sc, p.canon_n);
+            for (auto &m : p.modes) { names.push_back(m.name); ext.push_back(m.extent); }
+            std::unique_ptr<ctc_tc_plan> q(new ctc_tc_plan());
+            std::string e = ctc::build_plan(sa + "," + sb + "->" + sc, (int)names.size(), names.data(),
+                                            ext.data(), nullptr, nullptr, nullptr, p.dtype, q->plan);
+            if (!e.empty()) return fail(CTC_TC_EINVAL, e);
+            plan->packed = std::move(q);
+        }
+    }
+    auto ext_of = [&](const std::vector<int> &ids) {
+        std::vector<int64_t> e;
+        for (int id : ids) e.push_back(p.modes[id].extent);
+        return e;
+    };
+    std::vector<int64_t> ea = ext_of(p.a_modes), eb = ext_of(p.b_modes);
+    int rc = ctc_tc_permute(A, wa, (int)ea.size(), ea.data(), p.perm_a.data(), es, stream);
+    if (rc) return rc;
+    rc = ctc_tc_permute(B, wb, (int)eb.size(), eb.data(), p.perm_b.data(), es, stream);
+    if (rc) return rc;
+    rc = launch_plan(plan->packed.get(), alpha, wa, wb, 0.0, wc, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    // [batch,M,N] -> C
+    std::vector<int> gemm_order;
+    gemm_order.insert(gemm_order.end(), p.canon_batch.begin(), p.canon_batch.end());
+    gemm_order.insert(gemm_order.end(), p.canon_m.begin(), p.canon_m.end());
+    gemm_order.insert(gemm_order.end(), p.canon_n.begin(), p.canon_n.end());
+    std::vector<int64_t> eg = ext_of(gemm_order);
+    return ctc_tc_permute(wc, C, (int)eg.size(), eg.data(), p.perm_c.data(), es, stream);
+}
+
+int ctc_tc_fill(void *dev, int64_t n, uint64_t seed, int64_t first, int dtype, void *stream)
+{
+    if (!dev || n < 0) return fail(CTC_TC_EINVAL, "bad argument");
+    hipError_t e = ctc::launch_fill(dev, n, seed, first, dtype, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "fill kernel launch");
+    return CTC_TC_OK;
+}
+
+int ctc_tc_time_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta,
+                        void *C, void *stream, int warmup, int iters, double *avg_ms)
+{
+    if (!plan || !avg_ms || iters <= 0 || warmup < 0) return fail(CTC_TC_EINVAL, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < warmup; ++i) {
+        int rc = ctc_tc_execute(plan, alpha, A, B, beta, C, stream);
+        if (rc) return rc;
+    }
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0);
+    if (e != hipSuccess) return fail_hip(e, "hipEventCreate");
+    e = hipEventCreate(&e1);
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); return fail_hip(e, "hipEventCreate"); }
+    (void)hipEventRecord(e0, s);
+    int rc = CTC_TC_OK;
+    for (int i = 0; i < iters && rc == CTC_TC_OK; ++i) rc = ctc_tc_execute(plan, alpha, A, B, beta, C, stream);
+    (void)hipEventRecord(e1, s);
+    e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail_hip(e, "event timing");
+    *avg_ms = (double)ms / iters;
+    return CTC_TC_OK;
+}
+
+}  // extern "C"

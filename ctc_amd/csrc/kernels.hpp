@@ -1,0 +1,49 @@
+// Device-side entry points shared between the C ABI (api.cpp) and the kernel files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ctc {
+
+// One GEMM-shaped contraction.  All tables hold ELEMENT offsets:
+//   A(m,k) = A[bat_a[b] + row_a[m] + k_a[k]],  B(k,n) = B[bat_b[b] + k_b[k] + col_b[n]],
+//   C(m,n) = C[bat_c[b] + row_c[m] + col_c[n]].
+struct GemmParams {
+    const void *A = nullptr;
+    const void *B = nullptr;
+    void *C = nullptr;
+    const int64_t *row_a = nullptr, *k_a = nullptr, *k_b = nullptr, *col_b = nullptr;
+    const int64_t *row_c = nullptr, *col_c = nullptr;
+    const int64_t *bat_a = nullptr, *bat_b = nullptr, *bat_c = nullptr;
+    int64_t M = 0, N = 0, K = 0;
+    int batch = 1;
+    double alpha = 1.0, beta = 0.0;
+    int nbm = 0, nbn = 0, group = 8;
+};
+
+// dtype: 0 f64, 1 f32.  layouts: see ctc_tc_layout.  bm/bn select the tile.
+// Returns hipSuccess or the launch error; hipErrorInvalidValue for an
+// unsupported combination.
+hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
+                       hipStream_t stream);
+
+// Generic tiled permutation through element-offset tables (see permute_kernels.hip).
+struct PermuteParams {
+    const void *in = nullptr;
+    void *out = nullptr;
+    // x: fused index that is contiguous in the INPUT; y: fused index contiguous in the OUTPUT;
+    // o: everything else.
+    const int64_t *in_x = nullptr, *out_x = nullptr;
+    const int64_t *in_y = nullptr, *out_y = nullptr;
+    const int64_t *in_o = nullptr, *out_o = nullptr;
+    int64_t X = 1, Y = 1, O = 1;
+    int same_fast = 0;  // 1: input and output share their fastest mode (row copy)
+};
+hipError_t launch_permute(int elem_size, const PermuteParams &p, hipStream_t stream);
+
+hipError_t launch_fill(void *dev, int64_t n, uint64_t seed, int64_t first, int dtype,
+                       hipStream_t stream);
+
+}  // namespace ctc

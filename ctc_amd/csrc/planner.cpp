@@ -1,0 +1,345 @@
+// Contraction planner (host only).  See planner.hpp.
+#include "planner.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <sstream>
+
+namespace ctc {
+
+namespace {
+
+int find_mode(const Plan &p, char ch)
+{
+    for (size_t i = 0; i < p.modes.size(); ++i)
+        if (p.modes[i].name == ch) return (int)i;
+    return -1;
+}
+
+bool is_letter(char ch) { return (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z'); }
+
+std::string parse_operand(const std::string &text, Plan &p, std::vector<int> &out, bool may_add)
+{
+    out.clear();
+    for (char ch : text) {
+        if (ch == ' ') continue;
+        if (!is_letter(ch)) return std::string("malformed spec: unexpected character '") + ch + "'";
+        int id = find_mode(p, ch);
+        if (id < 0) {
+            if (!may_add) return std::string("malformed spec: output mode '") + ch + "' is in neither input";
+            if ((int)p.modes.size() >= kMaxModes) return "too many distinct modes";
+            Mode m;
+            m.name = ch;
+            p.modes.push_back(m);
+            id = (int)p.modes.size() - 1;
+        }
+        if (std::find(out.begin(), out.end(), id) != out.end())
+            return std::string("malformed spec: mode '") + ch + "' repeated inside one operand";
+        out.push_back(id);
+    }
+    return "";
+}
+
+int position_of(const std::vector<int> &v, int id)
+{
+    auto it = std::find(v.begin(), v.end(), id);
+    return it == v.end() ? -1 : (int)(it - v.begin());
+}
+
+void packed_strides(const Plan &p, const std::vector<int> &modes, std::vector<int64_t> &st)
+{
+    st.assign(modes.size(), 0);
+    int64_t s = 1;
+    for (int i = (int)modes.size() - 1; i >= 0; --i) {
+        st[i] = s;
+        s *= p.modes[modes[i]].extent;
+    }
+}
+
+// stable order of `ids` by ascending stride (fastest first), extent-1 modes dropped
+std::vector<int> fastest_first(const Plan &p, const std::vector<int> &ids,
+                               const std::vector<int64_t> &stride_of_mode)
+{
+    std::vector<int> v;
+    for (int id : ids)
+        if (p.modes[id].extent > 1) v.push_back(id);
+    std::stable_sort(v.begin(), v.end(),
+                     [&](int x, int y) { return stride_of_mode[x] < stride_of_mode[y]; });
+    return v;
+}
+
+int unit_stride_mode(const Plan &p, const std::vector<int> &operand_modes,
+                     const std::vector<int64_t> &stride_of_mode)
+{
+    for (int id : operand_modes)
+        if (p.modes[id].extent > 1 && stride_of_mode[id] == 1) return id;
+    return -1;
+}
+
+void build_table(const Plan &p, const std::vector<int> &order_fastest_first,
+                 const std::vector<int64_t> &stride_of_mode, int64_t count, std::vector<int64_t> &tab)
+{
+    tab.assign((size_t)count, 0);
+    std::vector<int64_t> idx(order_fastest_first.size(), 0);
+    int64_t off = 0;
+    for (int64_t i = 0; i < count; ++i) {
+        tab[(size_t)i] = off;
+        for (size_t d = 0; d < order_fastest_first.size(); ++d) {
+            int id = order_fastest_first[d];
+            off += stride_of_mode[id];
+            if (++idx[d] < p.modes[id].extent) break;
+            off -= idx[d] * stride_of_mode[id];
+            idx[d] = 0;
+        }
+    }
+}
+
+int vector_width(const Plan &p, const std::vector<int> &operand_modes,
+                 const std::vector<int64_t> &stride_of_mode, int unit_mode, int vmax)
+{
+    if (vmax <= 1 || unit_mode < 0) return 1;
+    if (p.modes[unit_mode].extent % vmax) return 1;
+    for (int id : operand_modes) {
+        if (id == unit_mode || p.modes[id].extent <= 1) continue;
+        if (stride_of_mode[id] % vmax) return 1;
+    }
+    return vmax;
+}
+
+void choose_tile(Plan &p)
+{
+    Tile t;
+    auto blocks = [&](int bm, int bn) {
+        return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch;
+    };
+    // Large tile when it still yields well over one block per CU; otherwise the
+    // small tile keeps the 256 CUs busy on modest problems.
+    if (p.M >= 96 && p.N >= 96 && blocks(128, 128) >= 384) {
+        t.bm = 128; t.bn = 128;
+    } else {
+        t.bm = 64; t.bn = 64;
+    }
+    t.bk = 16;
+    t.threads = 256;
+    t.group = 8;
+    p.tile = t;
+}
+
+}  // namespace
+
+std::string parse_and_classify(const std::string &spec, Plan &p)
+{
+    p = Plan();
+    p.spec = spec;
+    size_t comma = spec.find(',');
+    size_t arrow = spec.find("->");
+    size_t arrow_len = 2;
+    if (arrow == std::string::npos) {
+        arrow = spec.find('=');
+        arrow_len = 1;
+    }
+    if (comma == std::string::npos || arrow == std::string::npos || comma > arrow)
+        return "malformed spec: expected \"A,B->C\"";
+    std::string e;
+    if (!(e = parse_operand(spec.substr(0, comma), p, p.a_modes, true)).empty()) return e;
+    if (!(e = parse_operand(spec.substr(comma + 1, arrow - comma - 1), p, p.b_modes, true)).empty()) return e;
+    if (!(e = parse_operand(spec.substr(arrow + arrow_len), p, p.c_modes, false)).empty()) return e;
+
+    for (size_t id = 0; id < p.modes.size(); ++id) {
+        Mode &m = p.modes[id];
+        m.pa = position_of(p.a_modes, (int)id);
+        m.pb = position_of(p.b_modes, (int)id);
+        m.pc = position_of(p.c_modes, (int)id);
+        bool ia = m.pa >= 0, ib = m.pb >= 0, ic = m.pc >= 0;
+        if (ia && ib && ic) m.cls = kBatch;
+        else if (ia && ib) m.cls = kContracted;
+        else if (ia && ic) m.cls = kFreeM;
+        else if (ib && ic) m.cls = kFreeN;
+        else return std::string("mode '") + m.name + "' appears in one operand only";
+    }
+    for (int id : p.c_modes) {
+        int cls = p.modes[id].cls;
+        if (cls == kBatch) p.canon_batch.push_back(id);
+        else if (cls == kFreeM) p.canon_m.push_back(id);
+        else p.canon_n.push_back(id);
+    }
+    for (int id : p.a_modes)
+        if (p.modes[id].cls == kContracted) p.canon_k.push_back(id);
+
+    for (int id : p.canon_batch) p.perm_a.push_back(p.modes[id].pa);
+    for (int id : p.canon_m) p.perm_a.push_back(p.modes[id].pa);
+    for (int id : p.canon_k) p.perm_a.push_back(p.modes[id].pa);
+    for (int id : p.canon_batch) p.perm_b.push_back(p.modes[id].pb);
+    for (int id : p.canon_k) p.perm_b.push_back(p.modes[id].pb);
+    for (int id : p.canon_n) p.perm_b.push_back(p.modes[id].pb);
+    std::vector<int> gemm_order;
+    gemm_order.insert(gemm_order.end(), p.canon_batch.begin(), p.canon_batch.end());
+    gemm_order.insert(gemm_order.end(), p.canon_m.begin(), p.canon_m.end());
+    gemm_order.insert(gemm_order.end(), p.canon_n.begin(), p.canon_n.end());
+    for (int id : p.c_modes) p.perm_c.push_back(position_of(gemm_order, id));
+    return "";
+}
+
+std::string build_plan(const std::string &spec, int n_ext, const char *mode_names,
+                       const int64_t *extents, const int64_t *strides_a, const int64_t *strides_b,
+                       const int64_t *strides_c, int dtype, Plan &p)
+{
+    std::string e = parse_and_classify(spec, p);
+    if (!e.empty()) return e;
+    if (dtype != kF64 && dtype != kF32 && dtype != kBF16) return "unknown dtype";
+    p.dtype = dtype;
+    for (Mode &m : p.modes) {
+        m.extent = -1;
+        for (int j = 0; j < n_ext; ++j)
+            if (mode_names[j] == m.name) m.extent = extents[j];
+        if (m.extent < 0) return std::string("missing extent for mode '") + m.name + "'";
+        if (m.extent == 0) return std::string("zero extent for mode '") + m.name + "'";
+    }
+    std::vector<int64_t> st;
+    auto assign = [&](const std::vector<int> &modes, const int64_t *given, int which) {
+        if (given) st.assign(given, given + modes.size()); else packed_strides(p, modes, st);
+        for (size_t i = 0; i < modes.size(); ++i) {
+            Mode &m = p.modes[modes[i]];
+            (which == 0 ? m.sa : which == 1 ? m.sb : m.sc) = st[i];
+        }
+    };
+    assign(p.a_modes, strides_a, 0);
+    p.strides_a = st;
+    assign(p.b_modes, strides_b, 1);
+    p.strides_b = st;
+    assign(p.c_modes, strides_c, 2);
+    p.strides_c = st;
+    for (const Mode &m : p.modes)
+        if (m.sa < 0 || m.sb < 0 || m.sc < 0) return "negative strides are not supported";
+
+    auto count = [&](const std::vector<int> &modes) {
+        int64_t n = 1;
+        for (int id : modes) n *= p.modes[id].extent;
+        return n;
+    };
+    p.size_a = count(p.a_modes);
+    p.size_b = count(p.b_modes);
+    p.size_c = count(p.c_modes);
+
+    const size_t nm = p.modes.size();
+    std::vector<int64_t> sa(nm), sb(nm), sc(nm);
+    for (size_t i = 0; i < nm; ++i) {
+        sa[i] = p.modes[i].sa;
+        sb[i] = p.modes[i].sb;
+        sc[i] = p.modes[i].sc;
+    }
+
+    // Role assignment: the operand that owns C's unit-stride mode becomes GEMM "B",
+    // so that the MFMA result tile (lanes along N) stores contiguous runs of C.
+    int c_unit = unit_stride_mode(p, p.c_modes, sc);
+    p.swapped = (c_unit >= 0 && p.modes[c_unit].cls == kFreeM);
+    const std::vector<int64_t> &ga = p.swapped ? sb : sa;
+    const std::vector<int64_t> &gb = p.swapped ? sa : sb;
+    const std::vector<int> &ga_modes = p.swapped ? p.b_modes : p.a_modes;
+    const std::vector<int> &gb_modes = p.swapped ? p.a_modes : p.b_modes;
+    const std::vector<int> &m_ids = p.swapped ? p.canon_n : p.canon_m;
+    const std::vector<int> &n_ids = p.swapped ? p.canon_m : p.canon_n;
+
+    p.ex_n = fastest_first(p, n_ids, sc);
+    p.ex_m = fastest_first(p, m_ids, ga);
+    p.ex_batch = fastest_first(p, p.canon_batch, sc);
+    int a_unit = unit_stride_mode(p, ga_modes, ga);
+    int b_unit = unit_stride_mode(p, gb_modes, gb);
+    bool a_unit_is_k = a_unit >= 0 && p.modes[a_unit].cls == kContracted;
+    bool b_unit_is_k = b_unit >= 0 && p.modes[b_unit].cls == kContracted;
+    p.ex_k = fastest_first(p, p.canon_k, (a_unit_is_k || !b_unit_is_k) ? ga : gb);
+
+    p.M = count(p.ex_m);
+    p.N = count(p.ex_n);
+    p.K = count(p.ex_k);
+    p.batch = count(p.ex_batch);
+
+    const int vmax = 16 / dtype_size(dtype);
+    p.layout_a = kLayoutScalar;
+    p.vec_a = 1;
+    if (a_unit >= 0) {
+        int v = vector_width(p, ga_modes, ga, a_unit, vmax);
+        if (v > 1 && !p.ex_k.empty() && a_unit == p.ex_k[0]) { p.layout_a = kLayoutKVec; p.vec_a = v; }
+        else if (v > 1 && !p.ex_m.empty() && a_unit == p.ex_m[0]) { p.layout_a = kLayoutOuterVec; p.vec_a = v; }
+    }
+    p.layout_b = kLayoutScalar;
+    p.vec_b = 1;
+    if (b_unit >= 0) {
+        int v = vector_width(p, gb_modes, gb, b_unit, vmax);
+        if (v > 1 && !p.ex_k.empty() && b_unit == p.ex_k[0]) { p.layout_b = kLayoutKVec; p.vec_b = v; }
+        else if (v > 1 && !p.ex_n.empty() && b_unit == p.ex_n[0]) { p.layout_b = kLayoutOuterVec; p.vec_b = v; }
+    }
+
+    build_table(p, p.ex_m, ga, p.M, p.row_a);
+    build_table(p, p.ex_k, ga, p.K, p.k_a);
+    build_table(p, p.ex_k, gb, p.K, p.k_b);
+    build_table(p, p.ex_n, gb, p.N, p.col_b);
+    build_table(p, p.ex_m, sc, p.M, p.row_c);
+    build_table(p, p.ex_n, sc, p.N, p.col_c);
+    build_table(p, p.ex_batch, ga, p.batch, p.bat_a);
+    build_table(p, p.ex_batch, gb, p.batch, p.bat_b);
+    build_table(p, p.ex_batch, sc, p.batch, p.bat_c);
+
+    choose_tile(p);
+    return "";
+}
+
+std::string shard_plan(const Plan &full, char mode, int rank, int nranks, Plan &shard,
+                       int64_t &off_a, int64_t &off_b, int64_t &off_c)
+{
+    int id = find_mode(full, mode);
+    if (id < 0) return std::string("unknown mode '") + mode + "'";
+    if (nranks <= 0 || rank < 0 || rank >= nranks) return "bad rank/nranks";
+    const Mode &m = full.modes[id];
+    if (m.extent % nranks) return "extent of the sharded mode must be a multiple of the rank count";
+    std::string names;
+    std::vector<int64_t> ext;
+    for (const Mode &x : full.modes) {
+        names.push_back(x.name);
+        ext.push_back(x.name == mode ? x.extent / nranks : x.extent);
+    }
+    std::string e = build_plan(full.spec, (int)names.size(), names.data(), ext.data(),
+                               full.strides_a.data(), full.strides_b.data(), full.strides_c.data(),
+                               full.dtype, shard);
+    if (!e.empty()) return e;
+    int64_t first = (m.extent / nranks) * rank;
+    off_a = first * m.sa;
+    off_b = first * m.sb;
+    off_c = first * m.sc;
+    return "";
+}
+
+std::string describe(const Plan &p)
+{
+    static const char *cls_name[] = {"batch", "contracted", "free_m", "free_n"};
+    static const char *lay_name[] = {"k_vec", "outer_vec", "scalar"};
+    static const char *dt_name[] = {"f64", "f32", "bf16"};
+    std::ostringstream o;
+    o << "spec " << p.spec << " dtype " << dt_name[p.dtype] << "\n";
+    o << "modes";
+    for (const Mode &m : p.modes) o << " " << m.name << "=" << m.extent << ":" << cls_name[m.cls];
+    o << "\n";
+    auto names = [&](const std::vector<int> &v) {
+        std::string s;
+        for (int id : v) s.push_back(p.modes[id].name);
+        return s.empty() ? std::string("-") : s;
+    };
+    auto ints = [&](const std::vector<int> &v) {
+        std::string s;
+        for (size_t i = 0; i < v.size(); ++i) s += (i ? "," : "") + std::to_string(v[i]);
+        return s.empty() ? std::string("-") : s;
+    };
+    o << "canonical batch " << names(p.canon_batch) << " m " << names(p.canon_m) << " n "
+      << names(p.canon_n) << " k " << names(p.canon_k) << "\n";
+    o << "perm_a " << ints(p.perm_a) << " perm_b " << ints(p.perm_b) << " perm_c " << ints(p.perm_c) << "\n";
+    o << "exec swapped " << (p.swapped ? 1 : 0) << " batch " << names(p.ex_batch) << " m "
+      << names(p.ex_m) << " n " << names(p.ex_n) << " k " << names(p.ex_k) << " (fastest first)\n";
+    o << "gemm M " << p.M << " N " << p.N << " K " << p.K << " batch " << p.batch << "\n";
+    o << "layout_a " << lay_name[p.layout_a] << " vec " << p.vec_a << " layout_b "
+      << lay_name[p.layout_b] << " vec " << p.vec_b << "\n";
+    o << "tile " << p.tile.bm << "x" << p.tile.bn << "x" << p.tile.bk << " threads " << p.tile.threads
+      << " group " << p.tile.group << "\n";
+    return o.str();
+}
+
+}  // namespace ctc

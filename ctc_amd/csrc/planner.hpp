@@ -1,0 +1,71 @@
+// Contraction planner: host-only, no HIP types.  Turns an einsum-style spec plus
+// extents/strides into (1) a mode classification, (2) the canonical GEMM view and
+// its transposes, (3) the execution view used on the device: operand roles, mode
+// orders, per-dimension element-offset tables, operand layouts and a tile.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace ctc {
+
+constexpr int kMaxModes = 16;
+
+enum Dtype { kF64 = 0, kF32 = 1, kBF16 = 2 };
+enum ModeClass { kBatch = 0, kContracted = 1, kFreeM = 2, kFreeN = 3 };
+enum Layout { kLayoutKVec = 0, kLayoutOuterVec = 1, kLayoutScalar = 2 };
+
+inline int dtype_size(int dtype) { return dtype == kF64 ? 8 : (dtype == kF32 ? 4 : 2); }
+
+struct Mode {
+    char name = 0;
+    int cls = 0;
+    int64_t extent = 0;
+    // element strides in the ORIGINAL operands (0 when the operand lacks the mode)
+    int64_t sa = 0, sb = 0, sc = 0;
+    // positions in the original operands (-1 when absent)
+    int pa = -1, pb = -1, pc = -1;
+};
+
+struct Tile {
+    int bm = 128, bn = 128, bk = 16;
+    int threads = 256;
+    int group = 8;  // tile rows per L2-sharing group in the block order
+};
+
+struct Plan {
+    std::string spec;
+    int dtype = kF64;
+    std::vector<Mode> modes;           // distinct letters in order of first appearance
+    std::vector<int> a_modes, b_modes, c_modes;  // mode ids per operand position
+    std::vector<int64_t> strides_a, strides_b, strides_c;  // element strides per operand position
+
+    // canonical view (slowest first), independent of strides
+    std::vector<int> canon_batch, canon_m, canon_n, canon_k;
+    std::vector<int> perm_a, perm_b, perm_c;
+
+    // execution view (fastest first).  When `swapped`, GEMM operand "A" is the
+    // caller's B and vice versa, so that C's unit-stride mode is an N mode.
+    bool swapped = false;
+    std::vector<int> ex_batch, ex_m, ex_n, ex_k;
+    int64_t M = 1, N = 1, K = 1, batch = 1;
+    int layout_a = kLayoutScalar, layout_b = kLayoutScalar;
+    int vec_a = 1, vec_b = 1;
+    Tile tile;
+    std::vector<int64_t> row_a, k_a, k_b, col_b, row_c, col_c, bat_a, bat_b, bat_c;
+
+    int64_t size_a = 0, size_b = 0, size_c = 0;  // packed element counts (informational)
+};
+
+// All functions return "" on success or an error message.
+std::string parse_and_classify(const std::string &spec, Plan &plan);
+std::string build_plan(const std::string &spec, int n_ext, const char *mode_names,
+                       const int64_t *extents, const int64_t *strides_a, const int64_t *strides_b,
+                       const int64_t *strides_c, int dtype, Plan &plan);
+// Slab [rank*ext/nranks, (rank+1)*ext/nranks) of `mode`; offsets in elements.
+std::string shard_plan(const Plan &full, char mode, int rank, int nranks, Plan &shard,
+                       int64_t &off_a, int64_t &off_b, int64_t &off_c);
+std::string describe(const Plan &plan);
+
+}  // namespace ctc

@@ -1,0 +1,202 @@
+/*
+ * ctc_tc.h - C ABI of the MI355X (gfx950) tensor-contraction backend, libctc_tc.so.
+ *
+ * Where this sits relative to the reference (zjing14/CTC): the engine has no
+ * in-process operator table and no numeric API.  The only extension point it
+ * offers is the process boundary - a plugin XML whose <command> text is
+ * expanded (engine/src/ctc_plugin.cpp:166-206, engine/src/ctc_util.cpp:130-290)
+ * and handed to system() (engine/src/ctc_engine.cpp:160,285).  The executable
+ * `ctc_contract` that ships with this library is what such a plugin names; it is
+ * a thin argv front-end over the entry points below.  The engine's own C++ class
+ * headers (engine/include/ctc_engine.h:10-36, ctc_plugin.h:9-67) stay untouched.
+ * Because the reference has no contraction entry point, none of the functions
+ * below replaces a reference function one-for-one; each comment names the
+ * reference call site whose role it takes over, or says that there is none.
+ *
+ * Conventions
+ *   - plain C types only; every tensor pointer is a DEVICE pointer (HIP) unless
+ *     the name says host; the caller owns every buffer;
+ *   - return value 0 = success, negative = ctc_tc_status; the message of the
+ *     last failure on the calling thread is ctc_tc_last_error();
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     execution entry points only enqueue work and return;
+ *   - a plan is immutable after creation and may be used from several threads;
+ *   - tensors are dense with explicit element strides; strides == NULL means
+ *     packed with the LAST mode of the operand fastest.
+ */
+#ifndef CTC_TC_H
+#define CTC_TC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTC_TC_MAX_MODES 16
+
+typedef struct ctc_tc_plan ctc_tc_plan;
+
+enum ctc_tc_dtype { CTC_TC_F64 = 0, CTC_TC_F32 = 1, CTC_TC_BF16 = 2 };
+
+enum ctc_tc_status {
+    CTC_TC_OK = 0,
+    CTC_TC_EINVAL = -1,       /* bad argument */
+    CTC_TC_ESPEC = -2,        /* malformed contraction spec */
+    CTC_TC_EDEVICE = -3,      /* HIP runtime error or no gfx950 device */
+    CTC_TC_ENOMEM = -4,
+    CTC_TC_EUNSUPPORTED = -5, /* valid request this build cannot run */
+    CTC_TC_EALIGN = -6        /* operand pointer not aligned as the plan requires */
+};
+
+/* mode classes reported by ctc_tc_plan_get(CTC_TC_Q_CLASSES) */
+enum ctc_tc_mode_class {
+    CTC_TC_CLASS_BATCH = 0,      /* in A, B and C */
+    CTC_TC_CLASS_CONTRACTED = 1, /* in A and B only */
+    CTC_TC_CLASS_FREE_M = 2,     /* in A and C only */
+    CTC_TC_CLASS_FREE_N = 3      /* in B and C only */
+};
+
+/* integer outputs of the planner.  "mode ids" index the distinct letters of
+ * the spec in order of first appearance (A, then B, then C). */
+enum ctc_tc_query {
+    CTC_TC_Q_NAMES = 0,        /* one letter (as int) per distinct mode */
+    CTC_TC_Q_CLASSES = 1,      /* ctc_tc_mode_class per distinct mode */
+    CTC_TC_Q_EXTENTS = 2,
+    /* canonical GEMM view: batch/M/N in C order, K in A order (slowest first) */
+    CTC_TC_Q_CANON_BATCH = 3,
+    CTC_TC_Q_CANON_M = 4,
+    CTC_TC_Q_CANON_N = 5,
+    CTC_TC_Q_CANON_K = 6,
+    /* canonical transposes (position p of the result takes position perm[p]):
+     * A -> [batch,M,K], B -> [batch,K,N], [batch,M,N] -> C */
+    CTC_TC_Q_PERM_A = 7,
+    CTC_TC_Q_PERM_B = 8,
+    CTC_TC_Q_PERM_C = 9,
+    /* execution view chosen for the device (FASTEST mode first) */
+    CTC_TC_Q_SWAPPED = 10,     /* 1: operands exchanged so that C's unit-stride mode is an N mode */
+    CTC_TC_Q_EXEC_BATCH = 11,
+    CTC_TC_Q_EXEC_M = 12,
+    CTC_TC_Q_EXEC_N = 13,
+    CTC_TC_Q_EXEC_K = 14,
+    CTC_TC_Q_GEMM_DIMS = 15,   /* {M, N, K, batch} */
+    CTC_TC_Q_TILE = 16,        /* {BM, BN, BK, threads, layoutA, layoutB, vecA, vecB, group} */
+    /* element-offset tables of the execution view: address of GEMM element
+     * A(m,k) = A + ROW_A[m] + K_A[k] (+ BAT_A[b]), and so on */
+    CTC_TC_Q_ROW_A = 17,
+    CTC_TC_Q_K_A = 18,
+    CTC_TC_Q_K_B = 19,
+    CTC_TC_Q_COL_B = 20,
+    CTC_TC_Q_ROW_C = 21,
+    CTC_TC_Q_COL_C = 22,
+    CTC_TC_Q_BAT_A = 23,
+    CTC_TC_Q_BAT_B = 24,
+    CTC_TC_Q_BAT_C = 25,
+    CTC_TC_Q_FLOPS = 26        /* {2*M*N*K*batch} */
+};
+
+/* operand layouts reported in CTC_TC_Q_TILE */
+enum ctc_tc_layout {
+    CTC_TC_LAYOUT_K_VEC = 0,     /* unit stride along the fastest K mode, 16-byte loads */
+    CTC_TC_LAYOUT_OUTER_VEC = 1, /* unit stride along the fastest M (or N) mode, 16-byte loads */
+    CTC_TC_LAYOUT_SCALAR = 2     /* no usable unit stride: element loads */
+};
+
+/* Library version: major*10000 + minor*100 + patch.  No reference counterpart. */
+int ctc_tc_version(void);
+
+/* Message of the last failure on this thread ("" if none).  Takes the role of the
+ * engine's `throw "literal"` + top-level print (engine/src/execute_engine.cpp:96-99). */
+const char *ctc_tc_last_error(void);
+
+/* Number of usable HIP devices (0 when there is none; never fails). */
+int ctc_tc_device_count(void);
+
+/*
+ * Contraction planner (host only, needs no GPU).  spec is "aeim,ebmj->abij";
+ * mode_names/extents are parallel arrays of n_ext entries giving the extent of
+ * every letter.  No reference counterpart (the reference has no planner); it is
+ * reached from the plugin command line the engine builds in
+ * engine/src/ctc_plugin.cpp:175-206.
+ */
+int ctc_tc_plan_create(const char *spec, int n_ext, const char *mode_names, const int64_t *extents,
+                       const int64_t *strides_a, const int64_t *strides_b, const int64_t *strides_c,
+                       int dtype, ctc_tc_plan **plan);
+
+int ctc_tc_plan_destroy(ctc_tc_plan *plan);
+
+/* Human-readable plan (classes, orders, tile, kernel variant), NUL-terminated.
+ * Returns the length that would have been written.  Mirrors the role of
+ * Plugin::print / Workflow::print (engine/src/ctc_plugin.cpp:261-278). */
+int ctc_tc_plan_describe(const ctc_tc_plan *plan, char *buf, size_t buflen);
+
+/* Integer planner outputs.  Writes at most cap values, returns how many exist
+ * (negative on error). */
+int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_t cap);
+
+/*
+ * Plan for one shard of a contraction split along `mode` into nranks equal
+ * contiguous slabs (extent must divide evenly).  Element offsets of the slab
+ * inside the full A, B, C are returned in off_a/off_b/off_c (0 for an operand
+ * that does not hold the mode).  A free mode needs no exchange afterwards; a
+ * contracted mode leaves every rank with a full-size partial C to be summed
+ * (reduce-scatter / all-reduce by the caller).  No reference counterpart: the
+ * reference is single-device (apps/fastr/IndelRealigner.cpp:805-829).
+ */
+int ctc_tc_plan_shard(const ctc_tc_plan *plan, char mode, int rank, int nranks,
+                      ctc_tc_plan **shard, int64_t *off_a, int64_t *off_b, int64_t *off_c);
+
+/* Upload the plan's offset tables to the current device ahead of time, so that
+ * ctc_tc_execute allocates nothing later.  Optional. */
+int ctc_tc_plan_prepare(ctc_tc_plan *plan);
+
+/*
+ * C = alpha * contract(A, B) + beta * C on the current device, enqueued on
+ * `stream`.  A, B, C are device pointers to the plan's dtype.  Takes the role of
+ * the device launch in apps/fastr/IndelRealigner.cpp:805-829 (clean_gpu).
+ */
+int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B,
+                   double beta, void *C, void *stream);
+
+/*
+ * Mode permutation on the device: out mode p = in mode perm[p]; both packed,
+ * last mode fastest; elem_size 2, 4 or 8 bytes.  No reference counterpart.
+ */
+int ctc_tc_permute(const void *in, void *out, int rank, const int64_t *extents_in,
+                   const int *perm, int elem_size, void *stream);
+
+/*
+ * Explicit transpose-transpose-GEMM-transpose execution of the same plan
+ * through caller-provided workspace (bytes >= ctc_tc_ttgt_workspace_bytes):
+ * permutes A and B to [batch,M,K]/[batch,K,N], runs the GEMM on packed
+ * operands and permutes the result into C.  Exists to measure what the fused
+ * permute-on-load path saves.  No reference counterpart.
+ */
+int64_t ctc_tc_ttgt_workspace_bytes(const ctc_tc_plan *plan);
+int ctc_tc_execute_ttgt(ctc_tc_plan *plan, double alpha, const void *A, const void *B,
+                        double beta, void *C, void *workspace, int64_t workspace_bytes,
+                        void *stream);
+
+/*
+ * Synthetic operand generator on the device: element k (packed order) =
+ * uniform[-1,1) from splitmix64(seed + first + k), bit-identical to the CPU
+ * oracle's generator.  No reference counterpart.
+ */
+int ctc_tc_fill(void *dev, int64_t n, uint64_t seed, int64_t first, int dtype, void *stream);
+
+/*
+ * Average device time in milliseconds of `iters` back-to-back executions of the
+ * plan on `stream`, measured with HIP events recorded on that stream (after
+ * `warmup` untimed executions).  No reference counterpart; the reference's
+ * nearest analogue is its gettimeofday phase timers
+ * (apps/fastr/IndelRealigner.cpp:74-91).
+ */
+int ctc_tc_time_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B,
+                        double beta, void *C, void *stream, int warmup, int iters,
+                        double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTC_TC_H */

@@ -1,0 +1,37 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "contract_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import ref
+    ref.lib()
+    return ref
+
+
+@pytest.fixture(scope="session")
+def cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    import ctc_amd
+    if ctc_amd.device_count() < 1:
+        pytest.fail("libctc_tc.so sees no HIP device")
+    return torch.device("cuda:0")

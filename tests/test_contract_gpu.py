@@ -1,0 +1,189 @@
+"""Parity of the HIP contraction path (through the C ABI) with the CPU oracle.
+
+Tolerance: max |C_gpu - C_ref| <= tol * max |C_ref| with tol = 1e-12 (f64) and
+1e-5 (f32).  The oracle accumulates sequentially in f64; the kernel accumulates
+per K-tile inside the MFMA, so the results differ by summation order only."""
+import numpy as np
+import pytest
+import torch
+
+import ctc_amd
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f64": 1e-12, "f32": 1e-5}
+TDT = {"f64": torch.float64, "f32": torch.float32}
+CODE = {"f64": 0, "f32": 1}
+
+
+def _operands(oracle, spec, ext, dtype, dev, seed_a=0xC7C0A, seed_b=0xC7C0B):
+    ins, outm = spec.split("->")
+    la, lb = ins.split(",")
+    A = oracle.fill(int(np.prod([ext[c] for c in la])) if la else 1, seed_a, CODE[dtype])
+    B = oracle.fill(int(np.prod([ext[c] for c in lb])) if lb else 1, seed_b, CODE[dtype])
+    n_out = int(np.prod([ext[c] for c in outm])) if outm else 1
+    return A, B, n_out, torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+
+
+def _check(got, want, dtype):
+    got = got.astype(np.float64)
+    want = want.astype(np.float64)
+    err = np.abs(got - want).max()
+    scale = max(np.abs(want).max(), 1e-300)
+    assert err <= TOL[dtype] * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+def test_golden_cases(cuda, oracle, golden):
+    """Every committed vector, HIP path against the stored numpy.einsum samples and the oracle."""
+    for c in golden["cases"]:
+        if c["dtype"] not in TOL:
+            continue
+        dt = c["dtype"]
+        A, B, n_out, dA, dB = _operands(oracle, c["spec"], c["extents"], dt, cuda, c["seed_a"], c["seed_b"])
+        dC = torch.full((n_out,), float("nan"), dtype=TDT[dt], device=cuda)
+        ctc_amd.Plan(c["spec"], c["extents"], dt).execute(dA, dB, dC)
+        got = dC.cpu().numpy()
+        _check(got, oracle.contract(c["spec"], c["extents"], A, B, dtype=CODE[dt]), dt)
+        scale = float.fromhex(c["max_abs"])
+        for i, hx in c["samples"]:
+            assert abs(float(got[i]) - float.fromhex(hx)) <= 2 * TOL[dt] * scale, (c["name"], i)
+
+
+CASES = [
+    # name, spec, extents, dtype
+    ("ccsd_32", "aeim,ebmj->abij", dict(a=32, b=32, i=32, j=32, e=32, m=32), "f64"),
+    ("ccsd_ragged_tiles", "aeim,ebmj->abij", dict(a=13, b=11, i=10, j=14, e=7, m=6), "f64"),
+    ("ccsd_odd_scalar_loads", "aeim,ebmj->abij", dict(a=9, b=7, i=11, j=5, e=3, m=13), "f64"),
+    ("plain_gemm_edges", "ak,kb->ab", dict(a=130, b=70, k=50), "f64"),
+    ("gemm_tn", "ka,kb->ab", dict(a=96, b=64, k=40), "f64"),
+    ("gemm_nt", "ak,bk->ab", dict(a=96, b=64, k=40), "f64"),
+    ("gemm_c_transposed", "ak,kb->ba", dict(a=72, b=136, k=24), "f64"),
+    ("k_smaller_than_tile", "ak,kb->ab", dict(a=64, b=64, k=2), "f64"),
+    ("single_element", "ak,kb->ab", dict(a=1, b=1, k=1), "f64"),
+    ("outer_product", "a,b->ab", dict(a=70, b=130), "f64"),
+    ("matvec", "ak,k->a", dict(a=300, k=70), "f64"),
+    ("batched", "zak,zkb->zab", dict(z=5, a=40, b=72, k=24), "f64"),
+    ("batch_fastest", "akz,kbz->abz", dict(z=6, a=20, b=24, k=10), "f64"),
+    ("six_index", "adij,bcdk->abcijk", dict(a=6, b=5, c=4, i=6, j=4, k=8, d=16), "f64"),
+    ("adversarial", "dkca,bk->abcd", dict(a=32, b=8, c=12, d=32, k=8), "f32"),
+    ("ccsd_f32", "aeim,ebmj->abij", dict(a=24, b=24, i=24, j=24, e=24, m=24), "f32"),
+    ("ccsd_f32_scalar", "aeim,ebmj->abij", dict(a=6, b=7, i=5, j=9, e=3, m=10), "f32"),
+    ("hadamard_batch_only", "ab,ab->ab", dict(a=33, b=20), "f64"),
+]
+
+
+@pytest.mark.parametrize("name,spec,ext,dtype", CASES, ids=[c[0] for c in CASES])
+def test_against_oracle(cuda, oracle, name, spec, ext, dtype):
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, dtype, cuda)
+    dC = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+    ctc_amd.Plan(spec, ext, dtype).execute(dA, dB, dC)
+    _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE[dtype]), dtype)
+
+
+def test_alpha_beta(cuda, oracle):
+    spec, ext = "aeim,ebmj->abij", dict(a=12, b=10, i=8, j=6, e=4, m=8)
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, "f64", cuda)
+    C0 = oracle.fill(n_out, 99)
+    dC = torch.from_numpy(C0.copy()).to(cuda)
+    ctc_amd.Plan(spec, ext).execute(dA, dB, dC, alpha=0.75, beta=-1.5)
+    want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=0.75, beta=-1.5)
+    _check(dC.cpu().numpy(), want, "f64")
+
+
+def test_beta_zero_ignores_nan_in_c(cuda, oracle):
+    spec, ext = "ak,kb->ab", dict(a=40, b=24, k=16)
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, "f64", cuda)
+    dC = torch.full((n_out,), float("nan"), dtype=torch.float64, device=cuda)
+    ctc_amd.Plan(spec, ext).execute(dA, dB, dC, beta=0.0)
+    assert torch.isfinite(dC).all()
+
+
+def test_padded_strides_and_unaligned_base(cuda, oracle):
+    ext = dict(a=20, b=12, k=16)
+    A = oracle.fill(20 * 18 + 1, 5)
+    B = oracle.fill(16 * 12, 6)
+    want = oracle.contract("ak,kb->ab", ext, A[1:], B, strides_a=[18, 1])
+    dA = torch.from_numpy(A).to(cuda)
+    dB = torch.from_numpy(B).to(cuda)
+    dC = torch.zeros(20 * 12, dtype=torch.float64, device=cuda)
+    plan = ctc_amd.Plan("ak,kb->ab", ext, strides_a=[18, 1])
+    assert plan.summary()["layout_a"] == "k_vec"
+    # base pointer shifted by one element: only 8-byte aligned, forces element loads
+    plan.execute(dA[1:], dB, dC)
+    _check(dC.cpu().numpy(), want, "f64")
+
+
+def test_torch_tensor_front_end(cuda, oracle):
+    A = torch.from_numpy(oracle.fill(6 * 5 * 4, 1)).to(cuda).reshape(6, 5, 4)
+    B = torch.from_numpy(oracle.fill(5 * 7, 2)).to(cuda).reshape(5, 7)
+    got = ctc_amd.contract("adc,db->abc", A, B).cpu().numpy()
+    want = np.einsum("adc,db->abc", A.cpu().numpy(), B.cpu().numpy())
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    # non-contiguous view as an operand
+    got = ctc_amd.contract("dac,db->abc", A.permute(1, 0, 2), B).cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_ttgt_path_matches_fused_path(cuda, oracle):
+    spec, ext = "aeim,ebmj->abij", dict(a=12, b=10, i=8, j=6, e=4, m=8)
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, "f64", cuda)
+    plan = ctc_amd.Plan(spec, ext)
+    ws = torch.empty(plan.ttgt_workspace_bytes(), dtype=torch.uint8, device=cuda)
+    dC = torch.full((n_out,), float("nan"), dtype=torch.float64, device=cuda)
+    plan.execute_ttgt(dA, dB, dC, ws)
+    _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B), "f64")
+
+
+def test_sharded_execution_free_and_contracted(cuda, oracle):
+    spec, ext = "aeim,ebmj->abij", dict(a=8, b=6, i=6, j=8, e=4, m=6)
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, "f64", cuda)
+    want = oracle.contract(spec, ext, A, B)
+    full = ctc_amd.Plan(spec, ext)
+    dC = torch.full((n_out,), float("nan"), dtype=torch.float64, device=cuda)
+    for r in range(4):
+        sh, oa, ob, oc = full.shard("a", r, 4)
+        sh.execute(dA[oa:], dB[ob:], dC[oc:])
+    _check(dC.cpu().numpy(), want, "f64")
+    acc = torch.zeros(n_out, dtype=torch.float64, device=cuda)
+    for r in range(2):
+        sh, oa, ob, oc = full.shard("e", r, 2)
+        part = torch.empty(n_out, dtype=torch.float64, device=cuda)
+        sh.execute(dA[oa:], dB[ob:], part[oc:])
+        acc += part
+    _check(acc.cpu().numpy(), want, "f64")
+
+
+def test_device_generator_is_bit_identical(cuda, oracle):
+    for dt, code in ((torch.float64, 0), (torch.float32, 1), (torch.bfloat16, 2)):
+        x = torch.empty(10007, dtype=dt, device=cuda)
+        ctc_amd.fill(x, 0xC7C0A, first=5)
+        want = oracle.fill(10007, 0xC7C0A + 5, code)
+        got = x.view(torch.int16).cpu().numpy().view(np.uint16) if code == 2 else x.cpu().numpy()
+        assert np.array_equal(got, want)
+
+
+def test_headline_size_properties(cuda, oracle):
+    """N = 64 (BASELINE config 2): too big for the oracle in seconds, so check
+    (i) a free-index slab of it against the oracle and (ii) linearity in A."""
+    n = 64
+    spec, ext = "aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n)
+    dA = torch.empty(n ** 4, dtype=torch.float64, device=cuda)
+    dB = torch.empty(n ** 4, dtype=torch.float64, device=cuda)
+    ctc_amd.fill(dA, 0xC7C0A)
+    ctc_amd.fill(dB, 0xC7C0B)
+    dC = torch.empty(n ** 4, dtype=torch.float64, device=cuda)
+    plan = ctc_amd.Plan(spec, ext)
+    plan.execute(dA, dB, dC)
+    # (i) rows a = 5 and b in {0, 63}: C[5, b, :, :] recomputed by the oracle on the slab
+    A = oracle.fill(n ** 4, 0xC7C0A).reshape(n, n, n, n)
+    B = oracle.fill(n ** 4, 0xC7C0B).reshape(n, n, n, n)
+    for b in (0, 63):
+        sub = oracle.contract("aeim,ebmj->abij", dict(a=1, b=1, i=n, j=n, e=n, m=n),
+                              np.ascontiguousarray(A[5:6]).reshape(-1),
+                              np.ascontiguousarray(B[:, b:b + 1]).reshape(-1))
+        got = dC.reshape(n, n, n, n)[5, b].cpu().numpy().reshape(-1)
+        _check(got, sub, "f64")
+    # (ii) linearity: contract(2A, B) == 2 contract(A, B) exactly (power-of-two scaling)
+    dC2 = torch.empty_like(dC)
+    plan.execute(dA * 2.0, dB, dC2)
+    assert torch.equal(dC2, dC * 2.0)
