@@ -63,7 +63,11 @@ int upload_tables(ctc_tc_plan *pl, int device, DeviceTables &out)
         return CTC_TC_OK;
     }
     const ctc::Plan &p = pl->plan;
-    const std::vector<int64_t> *src[9] = {&p.row_a, &p.k_a, &p.k_b, &p.col_b, &p.row_c,
+    // k tables padded for the kernel's look-ahead (see kKTablePad)
+    std::vector<int64_t> k_a = p.k_a, k_b = p.k_b;
+    k_a.insert(k_a.end(), ctc::kKTablePad, k_a.back());
+    k_b.insert(k_b.end(), ctc::kKTablePad, k_b.back());
+    const std::vector<int64_t> *src[9] = {&p.row_a, &k_a, &k_b, &p.col_b, &p.row_c,
                                           &p.col_c, &p.bat_a, &p.bat_b, &p.bat_c};
     size_t total = 0;
     size_t start[9];

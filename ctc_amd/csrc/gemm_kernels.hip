@@ -17,9 +17,13 @@
 //
 // One workgroup = WM x WN waves; each wave owns a (BM/WM) x (BN/WN) block of C as
 // TM x TN accumulators of v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32.
-// Loop per K-tile: issue global loads of tile t+1 into registers, run the MFMAs of
-// tile t from LDS, write the registers into the other LDS buffer, one barrier.
+// Per K-tile the wave runs its MFMAs back to back and deals every other instruction
+// (fragment reads, LDS writes of the next tile, global loads of the tile after it)
+// out behind them, one barrier per tile; see tile_step below.
 #include "kernels.hpp"
+
+#include <cstdlib>
+#include <type_traits>
 
 namespace ctc {
 
@@ -66,6 +70,10 @@ template <typename V> __device__ __forceinline__ V zero_of()
 // Stages a BR x BK operand tile: global -> registers -> LDS.
 // "line": the dimension enumerated across passes (rows when K-major, k when outer-major);
 // "vector position": the dimension enumerated across neighbouring lanes.
+// Rows past the operand's extent are clamped to its last rows (their products land in
+// C elements that are never stored); only the K tail has to read as zero, and only in
+// the last K-tile, so the steady-state path carries no masking at all.  The k tables
+// are padded by the host with kKTablePad entries so lookups need no clamping.
 template <typename T, int LAY, int BR, int BK, int NT> struct Stager {
     static constexpr bool KMAJ = (LAY != kLayOuterVec);
     static constexpr int VEC = (LAY == kLayScalar) ? 1 : Traits<T>::VEC;
@@ -82,11 +90,8 @@ template <typename T, int LAY, int BR, int BK, int NT> struct Stager {
     static constexpr int NFIX = KMAJ ? NV : 1;
     static constexpr int NSTEP = KMAJ ? 1 : NV;
     int64_t fix_off[NFIX];
-    bool fix_ok[NFIX];
     int64_t step_off[NSTEP];
-    bool step_ok[NSTEP];
     vec_t regs[NV];
-    bool regs_ok[NV];  // validity of the tile held in regs (step_off may already describe a later tile)
     int vpos, line0;
 
     __device__ __forceinline__ void init(const int64_t *__restrict__ tab_rows, int64_t r0, int64_t R, int t)
@@ -95,42 +100,35 @@ template <typename T, int LAY, int BR, int BK, int NT> struct Stager {
         line0 = t / VPL;
 #pragma unroll
         for (int i = 0; i < NFIX; ++i) {
-            int64_t r = KMAJ ? r0 + line0 + i * LINES_PER_PASS : r0 + (int64_t)vpos * VEC;
-            fix_ok[i] = r < R;
-            int64_t rc = fix_ok[i] ? r : (R - VEC);
-            fix_off[i] = tab_rows[rc];
+            const int64_t r = KMAJ ? r0 + line0 + i * LINES_PER_PASS : r0 + (int64_t)vpos * VEC;
+            fix_off[i] = tab_rows[r < R ? r : (R - VEC)];
         }
     }
 
-    __device__ __forceinline__ void fetch_step(const int64_t *__restrict__ tab_k, int64_t k0, int64_t K)
+    __device__ __forceinline__ void fetch_step(const int64_t *__restrict__ tab_k, int64_t k0)
     {
 #pragma unroll
-        for (int i = 0; i < NSTEP; ++i) {
-            int64_t k = KMAJ ? k0 + (int64_t)vpos * VEC : k0 + line0 + i * LINES_PER_PASS;
-            step_ok[i] = k < K;
-            int64_t kc = step_ok[i] ? k : (K - VEC);
-            step_off[i] = tab_k[kc];
-        }
+        for (int i = 0; i < NSTEP; ++i)
+            step_off[i] = tab_k[KMAJ ? k0 + vpos * VEC : k0 + line0 + i * LINES_PER_PASS];
     }
 
-    __device__ __forceinline__ void issue(const T *__restrict__ base)
+    __device__ __forceinline__ void issue_one(int i, const T *__restrict__ base)
     {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int64_t off = fix_off[KMAJ ? i : 0] + step_off[KMAJ ? 0 : i];
-            regs_ok[i] = fix_ok[KMAJ ? i : 0] && step_ok[KMAJ ? 0 : i];
-            regs[i] = *reinterpret_cast<const vec_t *>(base + off);
-        }
+        const int64_t off = fix_off[KMAJ ? i : 0] + step_off[KMAJ ? 0 : i];
+        regs[i] = *reinterpret_cast<const vec_t *>(base + off);
     }
 
-    __device__ __forceinline__ void commit(T *__restrict__ lds)
+    // k0: first k of the tile held in regs; MASK_K: that tile crosses K
+    template <bool MASK_K>
+    __device__ __forceinline__ void commit_one(int i, T *__restrict__ lds, int64_t k0, int64_t K)
     {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            vec_t v = regs_ok[i] ? regs[i] : zero_of<vec_t>();
-            const int line = line0 + i * LINES_PER_PASS;
-            *reinterpret_cast<vec_t *>(lds + line * LDS_STRIDE + vpos * VEC) = v;
+        vec_t v = regs[i];
+        const int line = line0 + i * LINES_PER_PASS;
+        if (MASK_K) {
+            const int64_t k = KMAJ ? k0 + vpos * VEC : k0 + line;
+            if (k >= K) v = zero_of<vec_t>();
         }
+        *reinterpret_cast<vec_t *>(lds + line * LDS_STRIDE + vpos * VEC) = v;
     }
 
     // MFMA operand element for tile row rr (0..BR) and k index kq (0..BK)
@@ -146,6 +144,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM / 16;
     constexpr int TN = BN / WN / 16;
+    constexpr int NMFMA = TM * TN;  // MFMAs per k-step
     typedef Traits<T> Tr;
     typedef typename Tr::acc_t acc_t;
     typedef Stager<T, LA, BM, BK, NT> SA;
@@ -195,54 +194,126 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
         for (int j = 0; j < TN; ++j) acc[i][j] = zero_of<acc_t>();
 
     const int nk = (int)((p.K + BK - 1) / BK);
-
-    sa.fetch_step(p.k_a, 0, p.K);
-    sb.fetch_step(p.k_b, 0, p.K);
-    sa.issue(A);
-    sb.issue(B);
-    sa.commit(smem);
-    sb.commit(smem + SA::LDS_ELEMS);
-    if (nk > 1) {
-        sa.fetch_step(p.k_a, BK, p.K);
-        sb.fetch_step(p.k_b, BK, p.K);
-    }
-    __syncthreads();
-
+    const bool k_tail = (p.K % BK) != 0;
+    constexpr int KSTEPS = BK / 4;
+    static_assert(KSTEPS % 2 == 0, "fragment slots alternate per k-step");
     const int frow = lane & 15;
     const int fk = lane >> 4;
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // Prologue: tile 0 into LDS buffer 0, tile 1 on its way in registers, first
+    // fragments of tile 0 in registers.
+    sa.fetch_step(p.k_a, 0);
+    sb.fetch_step(p.k_b, 0);
+#pragma unroll
+    for (int i = 0; i < SA::NV; ++i) sa.issue_one(i, A);
+#pragma unroll
+    for (int i = 0; i < SB::NV; ++i) sb.issue_one(i, B);
+    sa.fetch_step(p.k_a, BK);
+    sb.fetch_step(p.k_b, BK);
+#pragma unroll
+    for (int i = 0; i < SA::NV; ++i) sa.template commit_one<true>(i, smem, 0, p.K);
+#pragma unroll
+    for (int i = 0; i < SB::NV; ++i) sb.template commit_one<true>(i, smem + SA::LDS_ELEMS, 0, p.K);
+    __syncthreads();
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < SA::NV; ++i) sa.issue_one(i, A);
+#pragma unroll
+        for (int i = 0; i < SB::NV; ++i) sb.issue_one(i, B);
+        sa.fetch_step(p.k_a, 2 * (int64_t)BK);
+        sb.fetch_step(p.k_b, 2 * (int64_t)BK);
+    }
+
+    T fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = SA::frag(smem, wm0 + 16 * i + frow, fk);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = SB::frag(smem + SA::LDS_ELEMS, wn0 + 16 * j + frow, fk);
+
+    // One K-tile.  A v_mfma_f64_16x16x4_f64 occupies the matrix pipe for 64 cycles, so
+    // every other instruction of the tile (LDS reads and writes, global loads, address
+    // arithmetic) is dealt out one or two at a time BEHIND an MFMA, in program order
+    // pinned with sched_barrier, instead of in clusters that would let the pipe drain:
+    //   k-steps 0..KSTEPS-2 : fragment reads of the next k-step;
+    //   k-step  KSTEPS-2    : also the LDS writes of tile kt+1 (registers -> other buffer);
+    //   barrier, then
+    //   k-step  KSTEPS-1    : first fragment reads of tile kt+1, global loads of tile
+    //                         kt+2 (a whole tile of MFMAs to land), k offsets of kt+3.
+    auto tile_step = [&](auto has1_t, auto has2_t, auto mask_t, int kt) {
+        constexpr bool HAS1 = decltype(has1_t)::value;  // tile kt+1 exists
+        constexpr bool HAS2 = decltype(has2_t)::value;  // tile kt+2 exists
+        constexpr bool MASK = decltype(mask_t)::value;  // tile kt+1 crosses K
         const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            sa.issue(A);
-            sb.issue(B);
-            if (kt + 2 < nk) {
-                // offsets for the tile after next: their latency hides under the MFMAs
-                sa.fetch_step(p.k_a, (int64_t)(kt + 2) * BK, p.K);
-                sb.fetch_step(p.k_b, (int64_t)(kt + 2) * BK, p.K);
-            }
-        }
         const T *la = smem + cur * STAGE_ELEMS;
         const T *lb = la + SA::LDS_ELEMS;
+        T *na = smem + (cur ^ 1) * STAGE_ELEMS;
+        T *nb = na + SA::LDS_ELEMS;
+        const int64_t k_next = (int64_t)(kt + 1) * BK;
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            T af[TM], bf[TN];
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            const int s = kk & 1;
+            const bool last = (kk == KSTEPS - 1);
+            if (last) __syncthreads();
+            const T *ra = last ? na : la;
+            const T *rb = last ? nb : lb;
+            const int kq = last ? fk : (kk + 1) * 4 + fk;
+            const bool do_reads = !last || HAS1;
+            const bool do_commit = (kk == KSTEPS - 2) && HAS1;
+            const bool do_issue = last && HAS2;
+            constexpr int NREAD = TM + TN;
+            constexpr int NUNIT = SA::NV + SB::NV;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = SA::frag(la, wm0 + 16 * i + frow, kk * 4 + fk);
+            for (int q = 0; q < NMFMA; ++q) {
+                acc[q / TN][q % TN] = Tr::mfma(fa[s][q / TN], fb[s][q % TN], acc[q / TN][q % TN]);
+                if (do_reads) {
+                    // fragment reads: the first NREAD/2 MFMAs each carry two
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = SB::frag(lb, wn0 + 16 * j + frow, kk * 4 + fk);
+                    for (int r = 0; r < NREAD; ++r) {
+                        if (r / 2 == q) {
+                            if (r < TM) fa[s ^ 1][r] = SA::frag(ra, wm0 + 16 * r + frow, kq);
+                            else fb[s ^ 1][r - TM] = SB::frag(rb, wn0 + 16 * (r - TM) + frow, kq);
+                        }
+                    }
+                }
+                if (do_commit || do_issue) {
+                    // staging units spread over the MFMAs that follow the fragment reads
+                    constexpr int Q0 = NREAD / 2 < NMFMA ? NREAD / 2 : 0;
+                    constexpr int QN = NMFMA - Q0;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Tr::mfma(af[i], bf[j], acc[i][j]);
+                    for (int u = 0; u < NUNIT; ++u) {
+                        if (Q0 + u * QN / NUNIT == q) {
+                            if (do_commit) {
+                                if (u < SA::NV) sa.template commit_one<MASK>(u, na, k_next, p.K);
+                                else sb.template commit_one<MASK>(u - SA::NV, nb, k_next, p.K);
+                            } else {
+                                if (u < SA::NV) sa.issue_one(u, A);
+                                else sb.issue_one(u - SA::NV, B);
+                            }
+                        }
+                    }
+                }
+                if (do_issue && q == NMFMA - 1) {
+                    sa.fetch_step(p.k_a, (int64_t)(kt + 3) * BK);
+                    sb.fetch_step(p.k_b, (int64_t)(kt + 3) * BK);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (more) {
-            T *na = smem + (cur ^ 1) * STAGE_ELEMS;
-            sa.commit(na);
-            sb.commit(na + SA::LDS_ELEMS);
+    };
+
+    {
+        const std::true_type yes;
+        const std::false_type no;
+        int kt = 0;
+        for (; kt + 2 < nk; ++kt) {
+            tile_step(yes, yes, no, kt);  // the tile committed here is never the last one
         }
-        __syncthreads();
+        if (kt + 1 < nk) {
+            if (k_tail) tile_step(yes, no, yes, kt);
+            else tile_step(yes, no, no, kt);
+            ++kt;
+        }
+        tile_step(no, no, no, kt);
     }
 
     // Epilogue: lanes 0..15 of each quarter-wave hold 16 consecutive N positions of
@@ -286,7 +357,9 @@ hipError_t launch_one(const GemmParams &p, hipStream_t stream)
     if (q.group < 1) q.group = 1;
     dim3 grid((unsigned)(q.nbm * q.nbn), (unsigned)p.batch, 1);
     dim3 block(64 * WM * WN, 1, 1);
-    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, BM, BN, BK, WM, WN>), grid, block, 0, stream, q);
+    // diagnostic knob: extra dynamic LDS per block lowers the number of co-resident blocks per CU
+    static const size_t extra_lds = getenv("CTC_TC_DEBUG_EXTRA_LDS") ? (size_t)atol(getenv("CTC_TC_DEBUG_EXTRA_LDS")) : 0;
+    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, BM, BN, BK, WM, WN>), grid, block, extra_lds, stream, q);
     return hipGetLastError();
 }
 

@@ -7,6 +7,10 @@
 
 namespace ctc {
 
+// The device copies of k_a and k_b carry this many extra entries (copies of the last
+// one) so that the kernel's look-ahead reads past K need no clamping.
+constexpr int kKTablePad = 64;
+
 // One GEMM-shaped contraction.  All tables hold ELEMENT offsets:
 //   A(m,k) = A[bat_a[b] + row_a[m] + k_a[k]],  B(k,n) = B[bat_b[b] + k_b[k] + col_b[n]],
 //   C(m,n) = C[bat_c[b] + row_c[m] + col_c[n]].
