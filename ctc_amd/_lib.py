@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libctc_tc.so")
+# CTC_TC_LIB points at another build of the same ABI (e.g. a diagnostic build)
+LIB_PATH = os.environ.get("CTC_TC_LIB") or os.path.join(_HERE, "lib", "libctc_tc.so")
 
 # every symbol include/ctc_tc.h declares
 SYMBOLS = (

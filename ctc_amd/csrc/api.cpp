@@ -64,9 +64,18 @@ int upload_tables(ctc_tc_plan *pl, int device, DeviceTables &out)
     }
     const ctc::Plan &p = pl->plan;
     // k tables padded for the kernel's look-ahead (see kKTablePad)
+    // Pad entry K+j repeats entry K-P+(j mod P), P = elements per 16-byte vector, so
+    // that a vector load through a pad entry re-reads the operand's last whole vector
+    // (same alignment, in bounds) instead of straddling the end of a row.
     std::vector<int64_t> k_a = p.k_a, k_b = p.k_b;
-    k_a.insert(k_a.end(), ctc::kKTablePad, k_a.back());
-    k_b.insert(k_b.end(), ctc::kKTablePad, k_b.back());
+    {
+        const int64_t vmax = 16 / ctc::dtype_size(p.dtype);
+        const int64_t period = (p.K % vmax == 0) ? vmax : 1;
+        for (int j = 0; j < ctc::kKTablePad; ++j) {
+            k_a.push_back(p.k_a[(size_t)(p.K - period + (j % period))]);
+            k_b.push_back(p.k_b[(size_t)(p.K - period + (j % period))]);
+        }
+    }
     const std::vector<int64_t> *src[9] = {&p.row_a, &k_a, &k_b, &p.col_b, &p.row_c,
                                           &p.col_c, &p.bat_a, &p.bat_b, &p.bat_c};
     size_t total = 0;

@@ -22,12 +22,30 @@
 // out behind them, one barrier per tile; see tile_step below.
 #include "kernels.hpp"
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 namespace ctc {
 
 namespace {
+
+// Diagnostic build (-DCTC_STAMPS): wave 0 of every block sums, per K-tile segment, the
+// shader-clock ticks it spends there and the launcher prints the median shares.
+// Never defined in the shipped library.
+#ifdef CTC_STAMPS
+__device__ unsigned long long g_stamp_sums[8 * 8192];
+#define CTC_STAMP(var)                                                                      \
+    do {                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    } while (0)
+#else
+#define CTC_STAMP(var) do { } while (0)
+#endif
 
 constexpr int kLayOuterVec = 1, kLayScalar = 2;
 
@@ -156,6 +174,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#ifdef CTC_STAMPS
+    unsigned long long st_entry, st_loop0, st_loop1;
+    const unsigned long long st_real0 = __builtin_amdgcn_s_memrealtime();
+    CTC_STAMP(st_entry);
+#endif
     const int wm0 = (wave / WN) * (TM * 16);
     const int wn0 = (wave % WN) * (TN * 16);
 
@@ -194,7 +217,6 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
         for (int j = 0; j < TN; ++j) acc[i][j] = zero_of<acc_t>();
 
     const int nk = (int)((p.K + BK - 1) / BK);
-    const bool k_tail = (p.K % BK) != 0;
     constexpr int KSTEPS = BK / 4;
     static_assert(KSTEPS % 2 == 0, "fragment slots alternate per k-step");
     const int frow = lane & 15;
@@ -215,14 +237,12 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
 #pragma unroll
     for (int i = 0; i < SB::NV; ++i) sb.template commit_one<true>(i, smem + SA::LDS_ELEMS, 0, p.K);
     __syncthreads();
-    if (nk > 1) {
 #pragma unroll
-        for (int i = 0; i < SA::NV; ++i) sa.issue_one(i, A);
+    for (int i = 0; i < SA::NV; ++i) sa.issue_one(i, A);
 #pragma unroll
-        for (int i = 0; i < SB::NV; ++i) sb.issue_one(i, B);
-        sa.fetch_step(p.k_a, 2 * (int64_t)BK);
-        sb.fetch_step(p.k_b, 2 * (int64_t)BK);
-    }
+    for (int i = 0; i < SB::NV; ++i) sb.issue_one(i, B);
+    sa.fetch_step(p.k_a, 2 * (int64_t)BK);
+    sb.fetch_step(p.k_b, 2 * (int64_t)BK);
 
     T fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -239,21 +259,37 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     //   barrier, then
     //   k-step  KSTEPS-1    : first fragment reads of tile kt+1, global loads of tile
     //                         kt+2 (a whole tile of MFMAs to land), k offsets of kt+3.
-    auto tile_step = [&](auto has1_t, auto has2_t, auto mask_t, int kt) {
-        constexpr bool HAS1 = decltype(has1_t)::value;  // tile kt+1 exists
-        constexpr bool HAS2 = decltype(has2_t)::value;  // tile kt+2 exists
-        constexpr bool MASK = decltype(mask_t)::value;  // tile kt+1 crosses K
+#ifdef CTC_STAMPS
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_n = 0;
+#endif
+    // Every tile runs the same instruction stream: past the last tile the look-ahead
+    // loads re-read the operand's last k (the padded k tables keep them in bounds) and
+    // land in an LDS buffer nobody reads, which is cheaper than peeling the loop.
+    auto tile_step = [&](auto mask_t, int kt) {
+        constexpr bool HAS1 = true, HAS2 = true;
+        constexpr bool MASK = decltype(mask_t)::value;  // tile kt+1 may cross K
         const int cur = kt & 1;
         const T *la = smem + cur * STAGE_ELEMS;
         const T *lb = la + SA::LDS_ELEMS;
         T *na = smem + (cur ^ 1) * STAGE_ELEMS;
         T *nb = na + SA::LDS_ELEMS;
         const int64_t k_next = (int64_t)(kt + 1) * BK;
+#ifdef CTC_STAMPS
+        unsigned long long t0, t1, t2, t3;
+        CTC_STAMP(t0);
+#endif
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             const int s = kk & 1;
             const bool last = (kk == KSTEPS - 1);
+#ifdef CTC_STAMPS
+            if (kk == KSTEPS - 2) CTC_STAMP(t1);
+            if (last) CTC_STAMP(t2);
+#endif
             if (last) __syncthreads();
+#ifdef CTC_STAMPS
+            if (last) CTC_STAMP(t3);
+#endif
             const T *ra = last ? na : la;
             const T *rb = last ? nb : lb;
             const int kq = last ? fk : (kk + 1) * 4 + fk;
@@ -299,25 +335,32 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#ifdef CTC_STAMPS
+        unsigned long long t4;
+        CTC_STAMP(t4);
+        st_a += t1 - t0; st_b += t2 - t1; st_c += t3 - t2; st_d += t4 - t3; st_n += 1;
+#endif
     };
 
+#ifdef CTC_STAMPS
+    CTC_STAMP(st_loop0);
+#endif
     {
-        const std::true_type yes;
-        const std::false_type no;
         int kt = 0;
-        for (; kt + 2 < nk; ++kt) {
-            tile_step(yes, yes, no, kt);  // the tile committed here is never the last one
-        }
+        for (; kt + 2 < nk; ++kt) tile_step(std::false_type(), kt);
         if (kt + 1 < nk) {
-            if (k_tail) tile_step(yes, no, yes, kt);
-            else tile_step(yes, no, no, kt);
+            tile_step(std::true_type(), kt);  // commits the last tile, which may cross K
             ++kt;
         }
-        tile_step(no, no, no, kt);
+        tile_step(std::false_type(), kt);
     }
+#ifdef CTC_STAMPS
+    CTC_STAMP(st_loop1);
+#endif
 
     // Epilogue: lanes 0..15 of each quarter-wave hold 16 consecutive N positions of
-    // one row, so every store instruction writes four contiguous runs of C.
+    // one row, so every store instruction writes four contiguous runs of C.  The
+    // beta test is hoisted so the common beta == 0 path is a straight run of stores.
     const T alpha = (T)p.alpha, beta = (T)p.beta;
     int64_t coff[TN];
     bool cok[TN];
@@ -327,24 +370,46 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
         cok[j] = n < p.N;
         coff[j] = p.col_c[cok[j] ? n : 0];
     }
+    auto store_rows = [&](auto with_beta_t) {
+        constexpr bool WITH_BETA = decltype(with_beta_t)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TM; ++i) {
+            int64_t roff[4];
+            bool rok[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t m = m0 + wm0 + 16 * i + Tr::acc_row(lane, r);
-            const bool rok = m < p.M;
-            const int64_t roff = p.row_c[rok ? m : 0];
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + wm0 + 16 * i + Tr::acc_row(lane, r);
+                rok[r] = m < p.M;
+                roff[r] = p.row_c[rok[r] ? m : 0];
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (rok && cok[j]) {
-                    T *dst = C + roff + coff[j];
-                    T v = alpha * acc[i][j][r];
-                    if (beta != (T)0) v += beta * *dst;
-                    *dst = v;
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (rok[r] && cok[j]) {
+                        T *dst = C + roff[r] + coff[j];
+                        T v = alpha * acc[i][j][r];
+                        if (WITH_BETA) v += beta * *dst;
+                        *dst = v;
+                    }
                 }
             }
         }
+    };
+    if (beta == (T)0) store_rows(std::false_type());
+    else store_rows(std::true_type());
+#ifdef CTC_STAMPS
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long st_exit;
+        CTC_STAMP(st_exit);
+        if (t == 0 && blockIdx.x < 8192 && blockIdx.y == 0) {
+            unsigned long long *o = g_stamp_sums + 8 * blockIdx.x;
+            o[0] = st_a; o[1] = st_b; o[2] = st_c; o[3] = (__builtin_amdgcn_s_memrealtime() - st_real0); o[4] = st_n;
+            o[5] = st_loop0 - st_entry; o[6] = st_loop1 - st_loop0; o[7] = st_exit - st_loop1;
+        }
     }
+#endif
 }
 
 template <typename T, int LA, int LB, int BM, int BN>
@@ -360,6 +425,34 @@ hipError_t launch_one(const GemmParams &p, hipStream_t stream)
     // diagnostic knob: extra dynamic LDS per block lowers the number of co-resident blocks per CU
     static const size_t extra_lds = getenv("CTC_TC_DEBUG_EXTRA_LDS") ? (size_t)atol(getenv("CTC_TC_DEBUG_EXTRA_LDS")) : 0;
     hipLaunchKernelGGL((gemm_kernel<T, LA, LB, BM, BN, BK, WM, WN>), grid, block, extra_lds, stream, q);
+#ifdef CTC_STAMPS
+    {
+        (void)hipStreamSynchronize(stream);
+        static std::vector<unsigned long long> h(8 * 8192);
+        (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_stamp_sums), h.size() * 8);
+        const int nb = std::min<int>(8192, q.nbm * q.nbn);
+        std::vector<double> seg[4];
+        for (int b = 0; b < nb; ++b)
+            for (int i = 0; i < 4; ++i) seg[i].push_back((double)h[8 * b + i] / (double)std::max<unsigned long long>(1, h[8 * b + 4]));
+        double med[4];
+        for (int i = 0; i < 4; ++i) { std::sort(seg[i].begin(), seg[i].end()); med[i] = seg[i][nb / 2]; }
+        std::vector<double> ph[3];
+        for (int b = 0; b < nb; ++b)
+            for (int i = 0; i < 3; ++i) ph[i].push_back((double)h[8 * b + 5 + i]);
+        for (int i = 0; i < 3; ++i) std::sort(ph[i].begin(), ph[i].end());
+        {
+            std::vector<double> clk;
+            for (int b = 0; b < nb; ++b)
+                clk.push_back((double)(h[8 * b + 5] + h[8 * b + 6] + h[8 * b + 7]) / (double)std::max<unsigned long long>(1, h[8 * b + 3]) * 100.0);
+            std::sort(clk.begin(), clk.end());
+            fprintf(stderr, "[stamps] shader clock MHz (min/median/max over blocks): %.0f / %.0f / %.0f\n", clk[0], clk[nb / 2], clk[nb - 1]);
+        }
+        fprintf(stderr, "[stamps] per block ticks (median/max): prologue %.0f/%.0f | loop %.0f/%.0f | epilogue %.0f/%.0f\n",
+                ph[0][nb / 2], ph[0][nb - 1], ph[1][nb / 2], ph[1][nb - 1], ph[2][nb / 2], ph[2][nb - 1]);
+        fprintf(stderr, "[stamps] per K-tile ticks (median over %d blocks): ksteps0..n-3 %.0f | commit kstep %.0f | barrier %.0f | issue kstep %.0f | total %.0f\n",
+                nb, med[0], med[1], med[2], med[3], med[0] + med[1] + med[2] + med[3]);
+    }
+#endif
     return hipGetLastError();
 }
 

@@ -7,8 +7,9 @@
 
 namespace ctc {
 
-// The device copies of k_a and k_b carry this many extra entries (copies of the last
-// one) so that the kernel's look-ahead reads past K need no clamping.
+// The device copies of k_a and k_b carry this many extra entries (repeating the last
+// whole 16-byte vector's entries) so that the kernel's look-ahead reads past K need
+// no clamping and stay inside the operand.
 constexpr int kKTablePad = 64;
 
 // One GEMM-shaped contraction.  All tables hold ELEMENT offsets:
