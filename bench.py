@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--extent", type=int, default=96, help="extent of every mode (64..96 in BASELINE)")
-    ap.add_argument("--cpu-extent", type=int, default=56, help="extent of the CPU-oracle sample")
+    ap.add_argument("--cpu-extent", type=int, default=96, help="extent of the CPU-oracle sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

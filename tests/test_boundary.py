@@ -1,0 +1,111 @@
+"""The drop-in boundary: the unchanged CTC engine expands a plugin template and system()s
+`ctc_contract`.  CPU tests pin the host-side mirror of the template language against command
+lines logged by the reference engine itself (tests/golden/boundary_golden.json, made by
+oracle/make_boundary_golden.py) and, when oracle/_ref/execute_engine is present, against the
+reference engine live.  The GPU test runs BASELINE config 1 for real through the engine."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from ctc_amd import engine_boundary as eb
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENGINE = os.path.join(ROOT, "oracle", "_ref", "execute_engine")
+TOOL = os.path.join(ROOT, "ctc_amd", "bin", "ctc_contract")
+
+
+def _golden():
+    with open(os.path.join(ROOT, "tests", "golden", "boundary_golden.json")) as f:
+        return json.load(f)
+
+
+def test_template_language_matches_reference_engine_vectors(tmp_path):
+    for i, case in enumerate(_golden()):
+        path = tmp_path / ("p%d.xml" % i)
+        path.write_text(case["xml"])
+        got = eb.Plugin(str(path)).exec_commands(case["params"], {"ENGINE_DIR": "<ROOT>/"})
+        assert got == case["commands"], case["plugin"]
+
+
+def test_template_errors():
+    with pytest.raises(eb.EngineError):
+        eb.resolve_word("$nope_not_defined_anywhere", {}, {}, env={})
+    with pytest.raises(eb.EngineError):
+        eb.resolve_stream("tool [$a == b --x", {"a": "b"}, {})
+    with pytest.raises(eb.EngineError):
+        eb.plugin_commands("contract", {"not_a_parameter": "1"})
+    assert eb.resolve_word("$HOME_X/bin", {}, {}, env={"HOME_X": "/h"}) == "/h/bin"
+
+
+def test_contract_plugin_command_line():
+    cmds = eb.plugin_commands("contract", dict(spec="adc,db=abc", extents="a=8,b=6,c=5,d=7",
+                                               input_a="/t/A.bin", input_b="/t/B.bin", output_c="/t/C.bin"))
+    assert len(cmds) == 1
+    words = cmds[0].split()
+    assert words[0].endswith("plugins/contract/../../../bin/ctc_contract")
+    assert os.path.realpath(words[0]) == os.path.realpath(TOOL)
+    assert words[1:] == ["--spec", "adc,db=abc", "--extents", "a=8,b=6,c=5,d=7", "--dtype", "f64", "--a", "/t/A.bin",
+                         "--b", "/t/B.bin", "--out", "/t/C.bin", "--alpha", "1", "--beta", "0", "--device", "0"]
+    cmds = eb.plugin_commands("contract", dict(spec="s", extents="e", input_a="a", input_b="b", output_c="c",
+                                               shard="a:1/4", dtype="f32"))
+    assert cmds[0].split()[-2:] == ["--shard", "a:1/4"] and "--dtype f32" in cmds[0]
+
+
+def test_cli_command_composition():
+    line = eb.cli_command("/oge", "plugin", ["contract", "--spec", "adc,db=abc"], test=True)
+    assert line == "execute_engine /oge --test --debug  --verbose  plugin  contract --spec adc,db=abc"
+    assert eb.cli_command("/oge", "workflow", ["w"]).split() == ["execute_engine", "/oge", "--debug", "--verbose", "workflow", "w"]
+
+
+def _engine_dry_run(plugin, params):
+    argv = [ENGINE, eb.ENGINE_ROOT, "--test", "plugin", plugin]
+    for k, v in params.items():
+        argv += ["--" + k, v]
+    log = subprocess.run(argv, capture_output=True, text=True, cwd=str(ROOT)).stdout
+    return re.findall(r'Executing: "(.*)"', log)
+
+
+@pytest.mark.skipif(not os.path.exists(ENGINE), reason="reference engine not built (oracle/build_ref.sh)")
+def test_reference_engine_dry_run_equals_mirror():
+    params = dict(spec="aeim,ebmj=abij", extents="a=64,b=64,e=64,i=64,j=64,m=64", input_a="/d/A", input_b="/d/B",
+                  output_c="/d/C", alpha="2.5", shard="e:3/8")
+    assert _engine_dry_run("contract", params) == eb.plugin_commands("contract", params)
+    params = dict(spec="adc,db=abc", extents="a=8,b=6,c=5,d=7", output_plan="/d/plan.txt")
+    assert _engine_dry_run("contract_plan", params) == eb.plugin_commands("contract_plan", params)
+
+
+@pytest.mark.skipif(not os.path.exists(ENGINE), reason="reference engine not built (oracle/build_ref.sh)")
+def test_plan_plugin_runs_on_cpu_through_the_engine(tmp_path, oracle):
+    """BASELINE config 1 plumbing without a GPU: the engine system()s ctc_contract --describe."""
+    out = tmp_path / "plan.txt"
+    subprocess.run([ENGINE, eb.ENGINE_ROOT, "plugin", "contract_plan", "--spec", "adc,db=abc", "--extents",
+                    "a=8,b=6,c=5,d=7", "--output_plan", str(out)], check=True, capture_output=True, cwd=str(tmp_path))
+    text = out.read_text()
+    o = oracle.classify("adc,db->abc")
+    assert "canonical batch - m %s n %s k %s" % (o["m"], o["n"], o["k"]) in text
+    assert "perm_a " + ",".join(map(str, o["perm_a"])) in text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ext", [dict(a=8, b=6, c=5, d=7), dict(a=32, b=48, c=16, d=24)])
+def test_config1_through_the_unchanged_engine(tmp_path, oracle, ext):
+    """C[a,b,c] = A[a,d,c] * B[d,b]: files in, engine -> system(ctc_contract) on the GPU, file out."""
+    if not os.path.exists(ENGINE):
+        pytest.fail("oracle/_ref/execute_engine missing: run oracle/build_ref.sh where /root/reference exists")
+    A = oracle.fill(ext["a"] * ext["d"] * ext["c"], 0xC7C0A)
+    B = oracle.fill(ext["d"] * ext["b"], 0xC7C0B)
+    A.tofile(tmp_path / "A.bin")
+    B.tofile(tmp_path / "B.bin")
+    extents = ",".join("%s=%d" % kv for kv in ext.items())
+    run = subprocess.run([ENGINE, eb.ENGINE_ROOT, "plugin", "contract", "--spec", "adc,db=abc", "--extents", extents,
+                          "--input_a", str(tmp_path / "A.bin"), "--input_b", str(tmp_path / "B.bin"),
+                          "--output_c", str(tmp_path / "C.bin")], capture_output=True, text=True, cwd=str(tmp_path))
+    assert os.path.exists(tmp_path / "C.bin"), run.stdout + run.stderr
+    got = np.fromfile(tmp_path / "C.bin", dtype=np.float64)
+    want = oracle.contract("adc,db->abc", ext, A, B)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
