@@ -1,0 +1,97 @@
+"""Secondary measurements (BASELINE configs 3 and 5, plus kernel variants).  The headline
+(config 2) lives in bench.py; this script prints one JSON line per measurement.
+
+  python benchmarks/run_configs.py [permute] [adversarial] [f32] [small] [ttgt]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import ctc_amd  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+DEV = torch.device("cuda:0")
+
+
+def time_ms(fn, warmup=3, iters=10):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def permute_case(shape, perm, dtype=torch.float32, name=None):
+    x = torch.empty(shape, dtype=dtype, device=DEV)
+    ctc_amd.fill(x.view(-1), 0xC7C0A)
+    out = torch.empty([shape[p] for p in perm], dtype=dtype, device=DEV)
+    ms = time_ms(lambda: ctc_amd.permute(x, perm, out=out))
+    nbytes = 2 * x.numel() * x.element_size()
+    y = torch.empty_like(x)
+    ms_copy = time_ms(lambda: y.copy_(x))
+    print(json.dumps({"workload": name or "permute %s perm %s %s" % (list(shape), list(perm), dtype),
+                      "ms": round(ms, 4), "GB/s": round(nbytes / ms * 1e-6, 1),
+                      "frac_hbm_peak": round(nbytes / ms * 1e-6 / HBM_PEAK_GBS, 4),
+                      "d2d_copy_GB/s": round(nbytes / ms_copy * 1e-6, 1),
+                      "algorithmic_bytes": nbytes}))
+
+
+def contraction_case(spec, ext, dtype, name, ttgt=False):
+    tdt = {"f64": torch.float64, "f32": torch.float32}[dtype]
+    ins, outm = spec.split("->")
+    la, lb = ins.split(",")
+    n = lambda s: int(torch.tensor([ext[c] for c in s]).prod()) if s else 1  # noqa: E731
+    A = torch.empty(n(la), dtype=tdt, device=DEV)
+    B = torch.empty(n(lb), dtype=tdt, device=DEV)
+    C = torch.empty(n(outm), dtype=tdt, device=DEV)
+    ctc_amd.fill(A, 0xC7C0A)
+    ctc_amd.fill(B, 0xC7C0B)
+    plan = ctc_amd.Plan(spec, ext, dtype)
+    if ttgt:
+        ws = torch.empty(plan.ttgt_workspace_bytes(), dtype=torch.uint8, device=DEV)
+        ms = time_ms(lambda: plan.execute_ttgt(A, B, C, ws))
+    else:
+        ms = plan.time(A, B, C, warmup=3, iters=10)
+    nbytes = (A.numel() + B.numel() + C.numel()) * A.element_size()
+    s = plan.summary()
+    print(json.dumps({"workload": name, "path": "ttgt" if ttgt else "fused", "ms": round(ms, 4),
+                      "TFLOP/s": round(plan.flops / ms * 1e-9, 3), "GB/s": round(nbytes / ms * 1e-6, 1),
+                      "frac_hbm_peak": round(nbytes / ms * 1e-6 / HBM_PEAK_GBS, 4),
+                      "gemm": [s["M"], s["N"], s["K"], s["batch_count"]], "tile": s["tile"],
+                      "layouts": [s["layout_a"], s["layout_b"]], "swapped": s["swapped"]}))
+
+
+def main():
+    what = set(sys.argv[1:]) or {"permute", "adversarial", "f32"}
+    if "permute" in what:
+        permute_case((128, 128, 128, 128), (3, 2, 1, 0), name="config3 pure permute dcba<-abcd fp32 128^4")
+        permute_case((128, 128, 128, 128), (3, 2, 1, 0), torch.float64, name="permute dcba<-abcd fp64 128^4")
+        permute_case((128, 128, 128, 128), (0, 1, 3, 2), name="permute abdc<-abcd fp32 128^4")
+        permute_case((128, 128, 128, 128), (1, 0, 2, 3), name="permute bacd<-abcd fp32 128^4 (row copy)")
+        permute_case((128, 8, 128, 128), (3, 1, 2, 0), name="permute akcd<-dkca fp32 (A of config 3)")
+    if "adversarial" in what:
+        ext = dict(a=128, b=8, c=128, d=128, k=8)
+        contraction_case("dkca,bk->abcd", ext, "f32", "config3 adversarial abcd=dkca,bk fp32")
+        contraction_case("dkca,bk->abcd", ext, "f32", "config3 adversarial abcd=dkca,bk fp32", ttgt=True)
+    if "f32" in what:
+        for n in (64, 96):
+            contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "f32", "ccsd fp32 extent %d" % n)
+    if "ttgt" in what:
+        n = 64
+        contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "f64", "ccsd fp64 extent 64", ttgt=True)
+        contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "f64", "ccsd fp64 extent 64")
+
+
+if __name__ == "__main__":
+    main()

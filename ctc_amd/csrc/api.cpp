@@ -152,6 +152,10 @@ int get_permute_tables(int device, int rank, const int64_t *extents, const int *
     t.params.Y = pp.Y;
     t.params.O = pp.O;
     t.params.same_fast = pp.same_fast ? 1 : 0;
+    for (int i = 0; i < 3; ++i) {
+        const int64_t v = 8 >> i;  // elements per 16 bytes for 2-, 4-, 8-byte elements
+        t.params.vec_ok[i] = (pp.fast_in_extent % v == 0 && pp.fast_out_extent % v == 0) ? 1 : 0;
+    }
     g_perm_cache[key] = t;
     out = t;
     return CTC_TC_OK;

@@ -45,6 +45,7 @@ struct PermuteParams {
     const int64_t *in_o = nullptr, *out_o = nullptr;
     int64_t X = 1, Y = 1, O = 1;
     int same_fast = 0;  // 1: input and output share their fastest mode (row copy)
+    int vec_ok[3] = {0, 0, 0};  // 16-byte vectors legal for 2-, 4-, 8-byte elements (index log2(size)-1)
 };
 hipError_t launch_permute(int elem_size, const PermuteParams &p, hipStream_t stream);
 

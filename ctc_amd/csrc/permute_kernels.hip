@@ -5,12 +5,21 @@
 //   x  - runs along the input's fastest modes  (input addresses contiguous in x)
 //   y  - runs along the output's fastest modes (output addresses contiguous in y)
 //   o  - every remaining mode
-// The tiled kernel moves a 64(x) x 64(y) patch through LDS: loads put the wave's
-// lanes along x (coalesced reads), stores put them along y (coalesced writes).
-// The LDS patch is padded to 65 columns so the transposed read touches each bank
-// once (4-byte elements) or each bank pair once (8-byte elements).
-// When input and output share their fastest mode there is nothing to transpose and
-// the row-copy kernel streams contiguous runs instead.
+//
+// Vector kernel (the fast path; 16-byte accesses on both sides).  V = 16 / element
+// size.  A workgroup moves a (16V x 16V) patch of (x, y): thread (vx, vq) loads the V
+// rows y = V*vq .. V*vq+V-1 as 16-byte vectors at x = V*vx, so 16 neighbouring lanes
+// read 256 contiguous bytes; it transposes its V x V micro-tile in registers and writes
+// V vectors into an LDS image indexed [x][y] whose 16-byte chunks are XOR-swizzled with
+// the row's vx, which makes both the writes (8 lanes: 8 different chunks) and the
+// reads (16 lanes of one row: 16 different chunks) bank-conflict free without padding.
+// In the store phase 16 neighbouring lanes write 256 contiguous bytes of the output.
+// A workgroup walks several consecutive `o` values with the same (x, y) patch so the
+// table entries are fetched once.
+//
+// Scalar kernel: the same patch scheme with element accesses and a padded LDS tile,
+// for extents or strides that do not allow 16-byte vectors.
+// Row kernels: input and output share their fastest mode, nothing to transpose.
 //
 // The fill kernel generates synthetic operands directly in HBM.
 #include "kernels.hpp"
@@ -21,6 +30,82 @@ namespace {
 
 constexpr int kTile = 64;
 constexpr int kThreads = 256;
+constexpr int kOPerBlock = 4;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename E>
+__global__ void __launch_bounds__(kThreads) permute_vec_kernel(const PermuteParams p, int ntx, int nty, int no)
+{
+    constexpr int V = 16 / sizeof(E);
+    constexpr int T = 16 * V;  // patch edge in elements; one LDS row = T * sizeof(E) = 256 bytes
+    __shared__ __attribute__((aligned(16))) E tile[T * T];
+
+    const int64_t bid = blockIdx.x;
+    const int tx = (int)(bid % ntx);
+    const int ty = (int)((bid / ntx) % nty);
+    const int64_t ob = bid / ((int64_t)ntx * nty);
+    const int64_t x0 = (int64_t)tx * T, y0 = (int64_t)ty * T;
+    const int lo = threadIdx.x & 15;  // vector index along the contiguous direction
+    const int hi = threadIdx.x >> 4;  // 0..15
+
+    // load side: x = x0 + V*lo, rows y = y0 + V*hi + r
+    const int64_t lx = x0 + (int64_t)V * lo;
+    const bool lx_ok = lx < p.X;
+    const int64_t in_xo = p.in_x[lx_ok ? lx : 0];
+    int64_t in_yo[V];
+    bool ly_ok[V];
+#pragma unroll
+    for (int r = 0; r < V; ++r) {
+        const int64_t y = y0 + (int64_t)V * hi + r;
+        ly_ok[r] = lx_ok && y < p.Y;
+        in_yo[r] = p.in_y[y < p.Y ? y : 0];
+    }
+    // store side: y = y0 + V*lo, rows x = x0 + hi + 16*r
+    const int64_t sy = y0 + (int64_t)V * lo;
+    const bool sy_ok = sy < p.Y;
+    const int64_t out_yo = p.out_y[sy_ok ? sy : 0];
+    int64_t out_xo[V];
+    bool sx_ok[V];
+#pragma unroll
+    for (int r = 0; r < V; ++r) {
+        const int64_t x = x0 + hi + 16 * r;
+        sx_ok[r] = sy_ok && x < p.X;
+        out_xo[r] = p.out_x[x < p.X ? x : 0];
+    }
+
+    const int64_t o_begin = ob * kOPerBlock;
+    const int64_t o_end = o_begin + kOPerBlock < p.O ? o_begin + kOPerBlock : p.O;
+    for (int64_t o = o_begin; o < o_end; ++o) {
+        const E *in = static_cast<const E *>(p.in) + p.in_o[o] + in_xo;
+        E *out = static_cast<E *>(p.out) + p.out_o[o] + out_yo;
+
+        union Vec { u32x4 v; E e[V]; };
+        Vec rows[V];
+#pragma unroll
+        for (int r = 0; r < V; ++r)
+            if (ly_ok[r]) rows[r].v = *reinterpret_cast<const u32x4 *>(in + in_yo[r]);
+        if (o != o_begin) __syncthreads();  // previous patch fully read back
+        // micro-tile transpose: column c of the V loaded rows becomes the vector for x = V*lo + c
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+            Vec col;
+#pragma unroll
+            for (int r = 0; r < V; ++r) col.e[r] = rows[r].e[c];
+            const int xr = V * lo + c;            // LDS row
+            const int chunk = hi ^ lo;            // y chunk V*hi.., swizzled with the row's vx
+            *reinterpret_cast<u32x4 *>(&tile[xr * T + chunk * V]) = col.v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < V; ++r) {
+            const int xr = hi + 16 * r;
+            const int chunk = lo ^ (xr / V);
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(&tile[xr * T + chunk * V]);
+            if (sx_ok[r]) *reinterpret_cast<u32x4 *>(out + out_xo[r]) = v;
+        }
+    }
+}
 
 template <typename E>
 __global__ void __launch_bounds__(kThreads) permute_tiled_kernel(const PermuteParams p, int ntx, int nty)
@@ -78,6 +163,29 @@ __global__ void __launch_bounds__(kThreads) permute_rows_kernel(const PermutePar
     }
 }
 
+// Same, 16 bytes per lane; X counts 16-byte vectors here and the tables are in elements.
+template <typename E>
+__global__ void __launch_bounds__(kThreads) permute_rows_vec_kernel(const PermuteParams p, int chunks)
+{
+    const int64_t bid = blockIdx.x;
+    const int64_t o = bid / chunks;
+    const int64_t x0 = (bid % chunks) * (int64_t)(kThreads * 4);
+    const u32x4 *in = reinterpret_cast<const u32x4 *>(static_cast<const E *>(p.in) + p.in_o[o]);
+    u32x4 *out = reinterpret_cast<u32x4 *>(static_cast<E *>(p.out) + p.out_o[o]);
+    const int64_t nvec = p.X / (16 / (int)sizeof(E));
+    u32x4 v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t x = x0 + threadIdx.x + r * kThreads;
+        if (x < nvec) v[r] = in[x];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t x = x0 + threadIdx.x + r * kThreads;
+        if (x < nvec) out[x] = v[r];
+    }
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
     uint64_t z = x + 0x9E3779B97F4A7C15ULL;
@@ -118,12 +226,26 @@ __global__ void fill_bf16_kernel(uint16_t *out, int64_t n, uint64_t seed)
 
 template <typename E> hipError_t launch_permute_t(const PermuteParams &p, hipStream_t stream)
 {
+    constexpr int V = 16 / (int)sizeof(E);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p.in) | reinterpret_cast<uintptr_t>(p.out)) & 15) == 0;
+    const bool vec = aligned && p.vec_ok[sizeof(E) == 2 ? 0 : sizeof(E) == 4 ? 1 : 2];
     if (p.same_fast) {
-        const int64_t chunks = (p.X + kThreads * 4 - 1) / (kThreads * 4);
+        const int64_t units = vec ? p.X / V : p.X;
+        const int64_t chunks = (units + kThreads * 4 - 1) / (kThreads * 4);
         const int64_t blocks = chunks * p.O;
         if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((permute_rows_kernel<E>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p,
-                           (int)chunks);
+        if (vec)
+            hipLaunchKernelGGL((permute_rows_vec_kernel<E>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, (int)chunks);
+        else
+            hipLaunchKernelGGL((permute_rows_kernel<E>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, (int)chunks);
+    } else if (vec) {
+        constexpr int T = 16 * V;
+        const int64_t ntx = (p.X + T - 1) / T, nty = (p.Y + T - 1) / T;
+        const int64_t no = (p.O + kOPerBlock - 1) / kOPerBlock;
+        const int64_t blocks = ntx * nty * no;
+        if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((permute_vec_kernel<E>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, (int)ntx,
+                           (int)nty, (int)no);
     } else {
         const int64_t ntx = (p.X + kTile - 1) / kTile, nty = (p.Y + kTile - 1) / kTile;
         const int64_t blocks = ntx * nty * p.O;

@@ -88,6 +88,10 @@ std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, P
         for (int p = r - 1; p >= 0; --p) { so[q[p]] = s; s *= ext[q[p]]; }
     }
 
+    if (r >= 1) {
+        pl.fast_in_extent = ext[r - 1];
+        pl.fast_out_extent = ext[q[r - 1]];
+    }
     std::vector<int> xm, ym, om;
     if (r <= 1 || q[r - 1] == r - 1) {
         pl.same_fast = true;

@@ -13,6 +13,9 @@ struct PermutePlan {
     bool same_fast = false;
     std::vector<int64_t> in_x, out_x, in_y, out_y, in_o, out_o;
     int64_t total = 0;
+    // extents of the (fused) fastest input and output modes: 16-byte vectors of V elements are
+    // legal on both sides when V divides both (every other stride is then a multiple of V too)
+    int64_t fast_in_extent = 1, fast_out_extent = 1;
     // fused problem, for reporting: extents (input order) and permutation
     std::vector<int64_t> fused_extents;
     std::vector<int> fused_perm;
