@@ -84,6 +84,9 @@ def main():
         ext = dict(a=128, b=8, c=128, d=128, k=8)
         contraction_case("dkca,bk->abcd", ext, "f32", "config3 adversarial abcd=dkca,bk fp32")
         contraction_case("dkca,bk->abcd", ext, "f32", "config3 adversarial abcd=dkca,bk fp32", ttgt=True)
+        # same contraction with c = 1024: 1.07 GB moved, four times the 256 MiB Infinity Cache
+        contraction_case("dkca,bk->abcd", dict(a=128, b=8, c=1024, d=128, k=8), "f32",
+                         "config3 adversarial, c=1024 (beyond the Infinity Cache)")
     if "f32" in what:
         for n in (64, 96):
             contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "f32", "ccsd fp32 extent %d" % n)

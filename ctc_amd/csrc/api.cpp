@@ -36,6 +36,7 @@ struct DeviceTables {
     int64_t *base = nullptr;
     const int64_t *row_a = nullptr, *k_a = nullptr, *k_b = nullptr, *col_b = nullptr;
     const int64_t *row_c = nullptr, *col_c = nullptr, *bat_a = nullptr, *bat_b = nullptr, *bat_c = nullptr;
+    const int64_t *sk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // bx cx by cy bo co
 };
 
 struct PermuteTables {
@@ -76,16 +77,18 @@ int upload_tables(ctc_tc_plan *pl, int device, DeviceTables &out)
             k_b.push_back(p.k_b[(size_t)(p.K - period + (j % period))]);
         }
     }
-    const std::vector<int64_t> *src[9] = {&p.row_a, &k_a, &k_b, &p.col_b, &p.row_c,
-                                          &p.col_c, &p.bat_a, &p.bat_b, &p.bat_c};
+    constexpr int NT = 15;
+    const std::vector<int64_t> *src[NT] = {&p.row_a, &k_a, &k_b, &p.col_b, &p.row_c,
+                                           &p.col_c, &p.bat_a, &p.bat_b, &p.bat_c,
+                                           &p.sk_bx, &p.sk_cx, &p.sk_by, &p.sk_cy, &p.sk_bo, &p.sk_co};
     size_t total = 0;
-    size_t start[9];
-    for (int i = 0; i < 9; ++i) {
+    size_t start[NT];
+    for (int i = 0; i < NT; ++i) {
         start[i] = total;
         total += (src[i]->size() + 1) & ~size_t(1);  // keep every table 16-byte aligned
     }
     std::vector<int64_t> host(total, 0);
-    for (int i = 0; i < 9; ++i) std::copy(src[i]->begin(), src[i]->end(), host.begin() + start[i]);
+    for (int i = 0; i < NT; ++i) std::copy(src[i]->begin(), src[i]->end(), host.begin() + start[i]);
     DeviceTables t;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&t.base), total * sizeof(int64_t));
     if (e != hipSuccess) return fail_hip(e, "hipMalloc(offset tables)");
@@ -103,6 +106,7 @@ int upload_tables(ctc_tc_plan *pl, int device, DeviceTables &out)
     t.bat_a = t.base + start[6];
     t.bat_b = t.base + start[7];
     t.bat_c = t.base + start[8];
+    for (int i = 0; i < 6; ++i) t.sk[i] = t.base + start[9 + i];
     pl->tables[device] = t;
     out = t;
     return CTC_TC_OK;
@@ -188,6 +192,30 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     rc = upload_tables(pl, device, t);
     if (rc) return rc;
 
+    if (p.batch > 65535) return fail(CTC_TC_EUNSUPPORTED, "more than 65535 batch entries");
+    const void *ga = p.swapped ? B : A, *gb = p.swapped ? A : B;
+    if (p.kernel != ctc::kKernelGemm &&
+        ((reinterpret_cast<uintptr_t>(gb) | reinterpret_cast<uintptr_t>(C)) & 15) == 0) {
+        ctc::SkinnyParams s;
+        s.A = ga; s.B = gb; s.C = C;
+        s.row_a = t.row_a; s.k_a = t.k_a; s.k_b = t.k_b; s.row_c = t.row_c;
+        s.bat_a = t.bat_a; s.bat_b = t.bat_b; s.bat_c = t.bat_c;
+        s.M = (int)p.M; s.K = (int)p.K; s.batch = (int)p.batch;
+        s.alpha = alpha; s.beta = beta;
+        if (p.kernel == ctc::kKernelSkinnyTranspose) {
+            s.transpose = 1;
+            s.bx = t.sk[0]; s.cx = t.sk[1]; s.by = t.sk[2]; s.cy = t.sk[3]; s.bo = t.sk[4]; s.co = t.sk[5];
+            s.X = p.sk_X; s.Y = p.sk_Y; s.O = p.sk_O;
+        } else {
+            s.transpose = 0;
+            s.bx = t.col_b; s.cx = t.col_c;
+            s.X = p.N;
+        }
+        hipError_t e = ctc::launch_skinny(p.dtype, s, stream);
+        if (e != hipSuccess) return fail_hip(e, "skinny contraction kernel launch");
+        return CTC_TC_OK;
+    }
+
     ctc::GemmParams g;
     g.A = p.swapped ? B : A;
     g.B = p.swapped ? A : B;
@@ -199,7 +227,6 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     g.batch = (int)p.batch;
     g.alpha = alpha; g.beta = beta;
     g.group = p.tile.group;
-    if (p.batch > 65535) return fail(CTC_TC_EUNSUPPORTED, "more than 65535 batch entries");
 
     // vector loads need 16-byte aligned bases; otherwise fall back to element loads
     int la = p.layout_a, lb = p.layout_b;
@@ -289,7 +316,7 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
     case CTC_TC_Q_GEMM_DIMS: v = {p.M, p.N, p.K, p.batch}; break;
     case CTC_TC_Q_TILE:
         v = {p.tile.bm, p.tile.bn, p.tile.bk, p.tile.threads, p.layout_a, p.layout_b,
-             p.vec_a, p.vec_b, p.tile.group};
+             p.vec_a, p.vec_b, p.tile.group, p.kernel};
         break;
     case CTC_TC_Q_ROW_A: return copy_out(p.row_a, out, cap);
     case CTC_TC_Q_K_A: return copy_out(p.k_a, out, cap);

@@ -34,6 +34,24 @@ struct GemmParams {
 hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
                        hipStream_t stream);
 
+// Skinny contraction C(m,n) = sum_k A(m,k) B(k,n) for M <= 16: streams B once and C once.
+// transpose == 0: n is the fused N index, B(k,n) = B[k_b[k] + nb[n]], C(m,n) = C[row_c[m] + nc[n]]
+//                 with nb = col_b, nc = col_c and X = N.
+// transpose == 1: n = (x, y, o); B offset = bx[x] + by[y] + bo[o], C offset = cx[x] + cy[y] + co[o].
+struct SkinnyParams {
+    const void *A = nullptr;
+    const void *B = nullptr;
+    void *C = nullptr;
+    const int64_t *row_a = nullptr, *k_a = nullptr, *k_b = nullptr, *row_c = nullptr;
+    const int64_t *bat_a = nullptr, *bat_b = nullptr, *bat_c = nullptr;
+    const int64_t *bx = nullptr, *cx = nullptr, *by = nullptr, *cy = nullptr, *bo = nullptr, *co = nullptr;
+    int64_t X = 1, Y = 1, O = 1;
+    int M = 1, K = 1, batch = 1;
+    int transpose = 0;
+    double alpha = 1.0, beta = 0.0;
+};
+hipError_t launch_skinny(int dtype, const SkinnyParams &p, hipStream_t stream);
+
 // Generic tiled permutation through element-offset tables (see permute_kernels.hip).
 struct PermuteParams {
     const void *in = nullptr;

@@ -281,6 +281,52 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
     build_table(p, p.ex_batch, sc, p.batch, p.bat_c);
 
     choose_tile(p);
+
+    // Skinny path: a handful of output rows over a long N.  Needs 16-byte vectors along
+    // an N mode in both B and C.
+    p.kernel = kKernelGemm;
+    const bool c_unit_in_n = c_unit >= 0 && p.modes[c_unit].cls != kBatch && p.modes[c_unit].cls != kContracted;
+    const bool b_unit_in_n = b_unit >= 0 && std::find(p.ex_n.begin(), p.ex_n.end(), b_unit) != p.ex_n.end();
+    if (p.M <= kSkinnyMaxM && p.M * p.K <= kSkinnyMaxMK && p.N >= 4096 && c_unit_in_n && b_unit_in_n) {
+        const int vb = vector_width(p, gb_modes, gb, b_unit, vmax);
+        const int vc = vector_width(p, p.c_modes, sc, c_unit, vmax);
+        if (vb == vmax && vc == vmax) {
+            if (b_unit == c_unit) {
+                p.kernel = kKernelSkinnySame;
+            } else {
+                p.kernel = kKernelSkinnyTranspose;
+                const int64_t want = 16 * vmax;  // patch edge
+                std::vector<int> by_b = fastest_first(p, p.ex_n, gb), by_c = p.ex_n;  // ex_n is in C order
+                std::vector<int> xm, ym, om;
+                std::vector<char> used(nm, 0);
+                int64_t vol = 1;
+                for (int id : by_c) {
+                    if (vol >= want || id == b_unit) break;
+                    ym.push_back(id);
+                    used[id] = 1;
+                    vol *= p.modes[id].extent;
+                }
+                vol = 1;
+                for (int id : by_b) {
+                    if (vol >= want || used[id]) break;
+                    xm.push_back(id);
+                    used[id] = 1;
+                    vol *= p.modes[id].extent;
+                }
+                for (int id : by_c)
+                    if (!used[id]) om.push_back(id);
+                p.sk_X = count(xm);
+                p.sk_Y = count(ym);
+                p.sk_O = count(om);
+                build_table(p, xm, gb, p.sk_X, p.sk_bx);
+                build_table(p, xm, sc, p.sk_X, p.sk_cx);
+                build_table(p, ym, gb, p.sk_Y, p.sk_by);
+                build_table(p, ym, sc, p.sk_Y, p.sk_cy);
+                build_table(p, om, gb, p.sk_O, p.sk_bo);
+                build_table(p, om, sc, p.sk_O, p.sk_co);
+            }
+        }
+    }
     return "";
 }
 
@@ -337,6 +383,10 @@ std::string describe(const Plan &p)
     o << "gemm M " << p.M << " N " << p.N << " K " << p.K << " batch " << p.batch << "\n";
     o << "layout_a " << lay_name[p.layout_a] << " vec " << p.vec_a << " layout_b "
       << lay_name[p.layout_b] << " vec " << p.vec_b << "\n";
+    static const char *kern_name[] = {"mfma_gemm", "skinny_same", "skinny_transpose"};
+    o << "kernel " << kern_name[p.kernel];
+    if (p.kernel == kKernelSkinnyTranspose) o << " x " << p.sk_X << " y " << p.sk_Y << " o " << p.sk_O;
+    o << "\n";
     o << "tile " << p.tile.bm << "x" << p.tile.bn << "x" << p.tile.bk << " threads " << p.tile.threads
       << " group " << p.tile.group << "\n";
     return o.str();

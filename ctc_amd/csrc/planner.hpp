@@ -15,6 +15,9 @@ constexpr int kMaxModes = 16;
 enum Dtype { kF64 = 0, kF32 = 1, kBF16 = 2 };
 enum ModeClass { kBatch = 0, kContracted = 1, kFreeM = 2, kFreeN = 3 };
 enum Layout { kLayoutKVec = 0, kLayoutOuterVec = 1, kLayoutScalar = 2 };
+enum KernelKind { kKernelGemm = 0, kKernelSkinnySame = 1, kKernelSkinnyTranspose = 2 };
+constexpr int kSkinnyMaxM = 16;
+constexpr int kSkinnyMaxMK = 2048;  // elements of the small operand kept in LDS
 
 inline int dtype_size(int dtype) { return dtype == kF64 ? 8 : (dtype == kF32 ? 4 : 2); }
 
@@ -54,6 +57,15 @@ struct Plan {
     int vec_a = 1, vec_b = 1;
     Tile tile;
     std::vector<int64_t> row_a, k_a, k_b, col_b, row_c, col_c, bat_a, bat_b, bat_c;
+
+    // Skinny path (M <= 16, K small, N large): memory-bound, no MFMA.  kSkinnySame:
+    // B and C share their unit-stride N mode, vectors run along the fused N index and
+    // col_b / col_c are used as they are.  kSkinnyTranspose: they differ; N is split
+    // into x (contiguous in B), y (contiguous in C) and o (the rest) with one offset
+    // table per operand, exactly as in a mode permutation.
+    int kernel = 0;  // KernelKind
+    int64_t sk_X = 1, sk_Y = 1, sk_O = 1;
+    std::vector<int64_t> sk_bx, sk_cx, sk_by, sk_cy, sk_bo, sk_co;
 
     int64_t size_a = 0, size_b = 0, size_c = 0;  // packed element counts (informational)
 };

@@ -13,6 +13,7 @@ _DTYPES = {"f64": F64, "f32": F32, "bf16": BF16, F64: F64, F32: F32, BF16: BF16}
 DTYPE_SIZE = {F64: 8, F32: 4, BF16: 2}
 CLASS_NAMES = {0: "batch", 1: "contracted", 2: "free_m", 3: "free_n"}
 LAYOUT_NAMES = {0: "k_vec", 1: "outer_vec", 2: "scalar"}
+KERNEL_NAMES = {0: "mfma_gemm", 1: "skinny_same", 2: "skinny_transpose"}
 
 
 def _dtype_code(dtype):
@@ -122,7 +123,7 @@ class Plan:
         return "".join(names[i] for i in self.get(query))
 
     def summary(self):
-        bm, bn, bk, threads, la, lb, va, vb, group = self.get(_lib.Q_TILE)
+        bm, bn, bk, threads, la, lb, va, vb, group, kernel = self.get(_lib.Q_TILE)
         m, n, k, batch = self.get(_lib.Q_GEMM_DIMS)
         return {
             "names": self.names,
@@ -137,7 +138,7 @@ class Plan:
             "M": m, "N": n, "K": k, "batch_count": batch,
             "tile": (bm, bn, bk), "threads": threads,
             "layout_a": LAYOUT_NAMES[la], "layout_b": LAYOUT_NAMES[lb], "vec_a": va, "vec_b": vb,
-            "group": group,
+            "group": group, "kernel": KERNEL_NAMES[kernel],
         }
 
     @property

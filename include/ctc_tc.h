@@ -81,7 +81,7 @@ enum ctc_tc_query {
     CTC_TC_Q_EXEC_N = 13,
     CTC_TC_Q_EXEC_K = 14,
     CTC_TC_Q_GEMM_DIMS = 15,   /* {M, N, K, batch} */
-    CTC_TC_Q_TILE = 16,        /* {BM, BN, BK, threads, layoutA, layoutB, vecA, vecB, group} */
+    CTC_TC_Q_TILE = 16,        /* {BM, BN, BK, threads, layoutA, layoutB, vecA, vecB, group, kernel} */
     /* element-offset tables of the execution view: address of GEMM element
      * A(m,k) = A + ROW_A[m] + K_A[k] (+ BAT_A[b]), and so on */
     CTC_TC_Q_ROW_A = 17,
@@ -101,6 +101,13 @@ enum ctc_tc_layout {
     CTC_TC_LAYOUT_K_VEC = 0,     /* unit stride along the fastest K mode, 16-byte loads */
     CTC_TC_LAYOUT_OUTER_VEC = 1, /* unit stride along the fastest M (or N) mode, 16-byte loads */
     CTC_TC_LAYOUT_SCALAR = 2     /* no usable unit stride: element loads */
+};
+
+/* kernel families reported in CTC_TC_Q_TILE */
+enum ctc_tc_kernel {
+    CTC_TC_KERNEL_MFMA_GEMM = 0,        /* LDS-tiled MFMA GEMM with permute-on-load */
+    CTC_TC_KERNEL_SKINNY_SAME = 1,      /* M <= 16 stream, B and C contiguous along the same N mode */
+    CTC_TC_KERNEL_SKINNY_TRANSPOSE = 2  /* M <= 16 stream, B and C contiguous along different N modes */
 };
 
 /* Library version: major*10000 + minor*100 + patch.  No reference counterpart. */

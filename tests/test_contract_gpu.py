@@ -69,6 +69,14 @@ CASES = [
     ("ccsd_f32", "aeim,ebmj->abij", dict(a=24, b=24, i=24, j=24, e=24, m=24), "f32"),
     ("ccsd_f32_scalar", "aeim,ebmj->abij", dict(a=6, b=7, i=5, j=9, e=3, m=10), "f32"),
     ("hadamard_batch_only", "ab,ab->ab", dict(a=33, b=20), "f64"),
+    # skinny kernels (M <= 16, long N)
+    ("skinny_transpose_ragged", "dkca,bk->abcd", dict(a=36, b=8, c=5, d=44, k=8), "f32"),
+    ("skinny_transpose_f64_m3", "dkca,bk->abcd", dict(a=34, b=3, c=7, d=66, k=5), "f64"),
+    ("skinny_transpose_m16", "dkca,bk->abcd", dict(a=64, b=16, c=2, d=64, k=12), "f32"),
+    ("skinny_same_f32", "kn,mk->mn", dict(m=8, n=40000, k=8), "f32"),
+    ("skinny_same_f64_m13", "kn,mk->mn", dict(m=13, n=8192, k=24), "f64"),
+    ("skinny_same_batched", "zkn,zmk->zmn", dict(z=3, m=4, n=4096, k=6), "f64"),
+    ("skinny_two_level_n", "kpq,mk->mpq", dict(m=5, p=70, q=72, k=9), "f64"),
 ]
 
 
@@ -78,6 +86,28 @@ def test_against_oracle(cuda, oracle, name, spec, ext, dtype):
     dC = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
     ctc_amd.Plan(spec, ext, dtype).execute(dA, dB, dC)
     _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE[dtype]), dtype)
+
+
+def test_skinny_cases_use_the_skinny_kernels():
+    kinds = {c[0]: ctc_amd.Plan(c[1], c[2], c[3]).summary()["kernel"] for c in CASES if c[0].startswith("skinny")}
+    assert kinds["skinny_transpose_ragged"] == "skinny_transpose"
+    assert kinds["skinny_transpose_f64_m3"] == "skinny_transpose"
+    assert kinds["skinny_same_f32"] == "skinny_same"
+    assert kinds["skinny_same_batched"] == "skinny_same"
+    assert ctc_amd.Plan("aeim,ebmj->abij", dict(a=32, b=32, i=32, j=32, e=32, m=32)).summary()["kernel"] == "mfma_gemm"
+
+
+@pytest.mark.parametrize("spec,ext,dtype", [
+    ("dkca,bk->abcd", dict(a=36, b=8, c=5, d=44, k=8), "f32"),
+    ("kn,mk->mn", dict(m=7, n=8192, k=10), "f64"),
+])
+def test_skinny_alpha_beta(cuda, oracle, spec, ext, dtype):
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, dtype, cuda)
+    C0 = oracle.fill(n_out, 99, CODE[dtype])
+    dC = torch.from_numpy(C0.copy()).to(cuda)
+    ctc_amd.Plan(spec, ext, dtype).execute(dA, dB, dC, alpha=0.5, beta=2.0)
+    want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=0.5, beta=2.0, dtype=CODE[dtype])
+    _check(dC.cpu().numpy(), want, dtype)
 
 
 def test_alpha_beta(cuda, oracle):
