@@ -90,6 +90,46 @@ def main():
     if "f32" in what:
         for n in (64, 96):
             contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "f32", "ccsd fp32 extent %d" % n)
+    if "six" in what:
+        # config 4: abcijk = adij, bcdk, free extents 40, d = 64; one GPU's slab of the free index a (5 of 40)
+        e = dict(a=5, b=40, c=40, i=40, j=40, k=40, d=64)
+        contraction_case("adij,bcdk->abcijk", e, "f64", "config4 slab a=5/40: abcijk=adij,bcdk fp64 (|C| 4.1 GB)")
+        e = dict(a=40, b=40, c=40, i=40, j=40, k=40, d=64)
+        contraction_case("adij,bcdk->abcijk", e, "f64", "config4 whole on one GPU (|C| 32.8 GB)")
+    if "small" in what:
+        import numpy as np
+        from oracle import ref
+        count, choices = 4096, [8, 16, 24, 32]
+        dims = []
+        for i in range(count):
+            x = ref.splitmix64(0xC7C05 + i)
+            dims.append((choices[x % 4], choices[(x >> 8) % 4], choices[(x >> 16) % 4]))
+        desc, na, nb, nc = ctc_amd.pack_small_problems(dims)
+        flops = sum(2 * m * n * k for m, n, k in dims)
+        dP = torch.from_numpy(desc.view(np.uint8).copy()).to(DEV)
+        for tdt, name in ((torch.float64, "f64"), (torch.float32, "f32")):
+            A = torch.empty(na, dtype=tdt, device=DEV)
+            B = torch.empty(nb, dtype=tdt, device=DEV)
+            C = torch.empty(nc, dtype=tdt, device=DEV)
+            ctc_amd.fill(A, 0xC7C05)
+            ctc_amd.fill(B, 0xC7C06)
+            ms = time_ms(lambda: ctc_amd.grouped_contract(dP, A, B, C), warmup=5, iters=50)
+            nbytes = (na + nb + nc) * A.element_size()
+            # the same problems one launch each (what a per-problem API would cost)
+            plans = {}
+            t0 = time.perf_counter()
+            sub = 256
+            for p, (m, n, k) in list(zip(desc, dims))[:sub]:
+                key = (m, n, k)
+                if key not in plans:
+                    plans[key] = ctc_amd.Plan("ak,kb->ab", dict(a=m, b=n, k=k), name)
+                plans[key].execute(A[int(p["off_a"]):], B[int(p["off_b"]):], C[int(p["off_c"]):])
+            torch.cuda.synchronize()
+            per_launch_ms = (time.perf_counter() - t0) / sub * count * 1e3
+            print(json.dumps({"workload": "config5 grouped: 4096 x (ab=ak,kb), extents in {8,16,24,32}, %s" % name,
+                              "launches": 1, "ms": round(ms, 4), "TFLOP/s": round(flops / ms * 1e-9, 3),
+                              "GB/s": round(nbytes / ms * 1e-6, 1), "flops": flops,
+                              "one_launch_per_problem_ms_extrapolated_from_%d" % sub: round(per_launch_ms, 2)}))
     if "ttgt" in what:
         n = 64
         contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "f64", "ccsd fp64 extent 64", ttgt=True)

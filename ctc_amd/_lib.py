@@ -16,6 +16,7 @@ SYMBOLS = (
     "ctc_tc_plan_create", "ctc_tc_plan_destroy", "ctc_tc_plan_describe", "ctc_tc_plan_get",
     "ctc_tc_plan_shard", "ctc_tc_plan_prepare", "ctc_tc_execute", "ctc_tc_permute",
     "ctc_tc_ttgt_workspace_bytes", "ctc_tc_execute_ttgt", "ctc_tc_fill", "ctc_tc_time_execute",
+    "ctc_tc_grouped_contract",
 )
 
 F64, F32, BF16 = 0, 1, 2
@@ -78,6 +79,8 @@ def load():
                                       ctypes.c_int64, vp]
     L.ctc_tc_fill.restype = ctypes.c_int
     L.ctc_tc_fill.argtypes = [vp, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int64, ctypes.c_int, vp]
+    L.ctc_tc_grouped_contract.restype = ctypes.c_int
+    L.ctc_tc_grouped_contract.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, vp, vp, ctypes.c_double, vp, vp]
     L.ctc_tc_time_execute.restype = ctypes.c_int
     L.ctc_tc_time_execute.argtypes = [vp, ctypes.c_double, vp, vp, ctypes.c_double, vp, vp,
                                       ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]

@@ -463,6 +463,18 @@ int ctc_tc_execute_ttgt(ctc_tc_plan *plan, double alpha, const void *A, const vo
     return ctc_tc_permute(wc, C, (int)eg.size(), eg.data(), p.perm_c.data(), es, stream);
 }
 
+int ctc_tc_grouped_contract(const ctc_tc_small_gemm *problems, int count, int dtype, double alpha, const void *A,
+                            const void *B, double beta, void *C, void *stream)
+{
+    static_assert(sizeof(ctc_tc_small_gemm) == sizeof(ctc::SmallGemm), "descriptor layouts must agree");
+    if (count < 0 || (count > 0 && (!problems || !A || !B || !C))) return fail(CTC_TC_EINVAL, "bad argument");
+    if (dtype != CTC_TC_F64 && dtype != CTC_TC_F32) return fail(CTC_TC_EUNSUPPORTED, "grouped contractions: f64 or f32");
+    hipError_t e = ctc::launch_grouped(dtype, reinterpret_cast<const ctc::SmallGemm *>(problems), count, A, B, C,
+                                       alpha, beta, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "grouped contraction kernel launch");
+    return CTC_TC_OK;
+}
+
 int ctc_tc_fill(void *dev, int64_t n, uint64_t seed, int64_t first, int dtype, void *stream)
 {
     if (!dev || n < 0) return fail(CTC_TC_EINVAL, "bad argument");

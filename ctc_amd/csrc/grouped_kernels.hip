@@ -1,0 +1,111 @@
+// Grouped small contractions on gfx950: many independent C_p = alpha * A_p * B_p + beta * C_p
+// (ab = ak,kb) with extents of a few tens, all in ONE launch.  Each problem is far too
+// small to fill a workgroup, so one wave owns one problem at a time and walks a
+// grid-stride list of problems.  Operands are not staged through LDS: for a 16x16x4 MFMA
+// the B fragment of lane l is B[4kk + (l>>4)][16j + (l&15)], i.e. 16 neighbouring lanes
+// read 16 consecutive elements of a row, and a problem's whole footprint (<= 3 * 32 * 32
+// elements) lives in L1/L2 after first touch.  The wave covers the output in 32 x 32
+// blocks of 2 x 2 MFMA accumulators; extents need not be multiples of anything.
+#include "kernels.hpp"
+
+namespace ctc {
+
+namespace {
+
+template <typename T> struct Mf;
+template <> struct Mf<double> {
+    typedef double acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int acc_row(int lane, int j) { return (lane >> 4) + 4 * j; }
+};
+template <> struct Mf<float> {
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int acc_row(int lane, int j) { return (lane >> 4) * 4 + j; }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) grouped_kernel(const SmallGemm *__restrict__ problems, int count, const T *A,
+                                                      const T *B, T *C, T alpha, T beta)
+{
+    typedef typename Mf<T>::acc_t acc_t;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+
+    for (int pi = wave; pi < count; pi += nwaves) {
+        const SmallGemm g = problems[pi];
+        const T *a = A + g.off_a;
+        const T *b = B + g.off_b;
+        T *c = C + g.off_c;
+        for (int m0 = 0; m0 < g.m; m0 += 32) {
+            for (int n0 = 0; n0 < g.n; n0 += 32) {
+                acc_t acc[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+                const int r0 = m0 + fr, r1 = m0 + 16 + fr;
+                const int c0 = n0 + fr, c1 = n0 + 16 + fr;
+                const bool r0ok = r0 < g.m, r1ok = r1 < g.m, c0ok = c0 < g.n, c1ok = c1 < g.n;
+                const T *a0 = a + (int64_t)(r0ok ? r0 : 0) * g.lda;
+                const T *a1 = a + (int64_t)(r1ok ? r1 : 0) * g.lda;
+                for (int k0 = 0; k0 < g.k; k0 += 4) {
+                    const int k = k0 + fk;
+                    const bool kok = k < g.k;
+                    const int kc = kok ? k : 0;
+                    const T *brow = b + (int64_t)kc * g.ldb;
+                    T fa0 = a0[kc], fa1 = a1[kc];
+                    T fb0 = brow[c0ok ? c0 : 0], fb1 = brow[c1ok ? c1 : 0];
+                    // zero what lies outside the problem: k tail in both operands, rows/columns past the edge
+                    if (!(kok && r0ok)) fa0 = 0;
+                    if (!(kok && r1ok)) fa1 = 0;
+                    if (!(kok && c0ok)) fb0 = 0;
+                    if (!(kok && c1ok)) fb1 = 0;
+                    acc[0][0] = Mf<T>::mfma(fa0, fb0, acc[0][0]);
+                    acc[0][1] = Mf<T>::mfma(fa0, fb1, acc[0][1]);
+                    acc[1][0] = Mf<T>::mfma(fa1, fb0, acc[1][0]);
+                    acc[1][1] = Mf<T>::mfma(fa1, fb1, acc[1][1]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = m0 + 16 * i + Mf<T>::acc_row(lane, r);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int col = n0 + 16 * j + fr;
+                            if (row < g.m && col < g.n) {
+                                T *dst = c + (int64_t)row * g.ldc + col;
+                                T v = alpha * acc[i][j][r];
+                                if (beta != (T)0) v += beta * *dst;
+                                *dst = v;
+                            }
+                        }
+                    }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_grouped(int dtype, const SmallGemm *problems, int count, const void *A, const void *B, void *C,
+                          double alpha, double beta, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    int blocks = (count + 3) / 4;  // four waves per workgroup, one problem per wave and pass
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (dtype == 0)
+        hipLaunchKernelGGL(grouped_kernel<double>, dim3(blocks), dim3(256), 0, stream, problems, count,
+                           static_cast<const double *>(A), static_cast<const double *>(B), static_cast<double *>(C), alpha, beta);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(grouped_kernel<float>, dim3(blocks), dim3(256), 0, stream, problems, count,
+                           static_cast<const float *>(A), static_cast<const float *>(B), static_cast<float *>(C), (float)alpha, (float)beta);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace ctc

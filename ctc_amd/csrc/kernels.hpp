@@ -52,6 +52,15 @@ struct SkinnyParams {
 };
 hipError_t launch_skinny(int dtype, const SkinnyParams &p, hipStream_t stream);
 
+// One small row-major GEMM of a grouped launch; layout shared with ctc_tc_small_gemm (ctc_tc.h).
+struct SmallGemm {
+    int32_t m, n, k;
+    int32_t lda, ldb, ldc;
+    int64_t off_a, off_b, off_c;
+};
+hipError_t launch_grouped(int dtype, const SmallGemm *problems_device, int count, const void *A, const void *B,
+                          void *C, double alpha, double beta, hipStream_t stream);
+
 // Generic tiled permutation through element-offset tables (see permute_kernels.hip).
 struct PermuteParams {
     const void *in = nullptr;

@@ -224,5 +224,33 @@ def fill(x, seed, first=0, stream=None):
     return x
 
 
+SMALL_GEMM_DTYPE = [("m", "<i4"), ("n", "<i4"), ("k", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"),
+                    ("off_a", "<i8"), ("off_b", "<i8"), ("off_c", "<i8")]
+
+
+def pack_small_problems(dims):
+    """Descriptors (numpy structured array, layout of ctc_tc_small_gemm) for packed row-major problems
+    laid out back to back; dims is a sequence of (m, n, k).  Returns (descriptors, |A|, |B|, |C|)."""
+    import numpy as np
+    d = np.zeros(len(dims), dtype=SMALL_GEMM_DTYPE)
+    oa = ob = oc = 0
+    for i, (m, n, k) in enumerate(dims):
+        d[i] = (m, n, k, k, n, n, oa, ob, oc)
+        oa += m * k
+        ob += k * n
+        oc += m * n
+    return d, oa, ob, oc
+
+
+def grouped_contract(problems, A, B, C, alpha=1.0, beta=0.0, stream=None):
+    """All small contractions ab = ak,kb described by `problems` (device tensor holding
+    ctc_tc_small_gemm descriptors, e.g. torch.from_numpy(desc.view(numpy.uint8)).cuda()) in one launch."""
+    L = _lib.load()
+    count = problems.numel() * problems.element_size() // 48
+    check(L.ctc_tc_grouped_contract(_ptr(problems), count, _dtype_code(A.dtype), float(alpha), _ptr(A), _ptr(B),
+                                    float(beta), _ptr(C), _stream(stream)))
+    return C
+
+
 def device_count():
     return int(_lib.load().ctc_tc_device_count())

@@ -186,6 +186,23 @@ int ctc_tc_execute_ttgt(ctc_tc_plan *plan, double alpha, const void *A, const vo
                         void *stream);
 
 /*
+ * Grouped small contractions (ab = ak,kb per problem) in ONE launch: problem p computes
+ * C_p[m x n] = alpha * A_p[m x k] * B_p[k x n] + beta * C_p, row-major with leading
+ * dimensions, at element offsets off_a/off_b/off_c from the common bases A, B, C.
+ * `problems` is a DEVICE array of `count` descriptors.  Extents are arbitrary (meant to be
+ * a few tens).  The nearest thing in the reference is the way FASTR batches >= 32 regions
+ * into one device launch (apps/fastr/IndelRealigner.cpp:93-94,1305-1313,805-829).
+ */
+typedef struct ctc_tc_small_gemm {
+    int32_t m, n, k;
+    int32_t lda, ldb, ldc;
+    int64_t off_a, off_b, off_c;
+} ctc_tc_small_gemm;
+
+int ctc_tc_grouped_contract(const ctc_tc_small_gemm *problems, int count, int dtype, double alpha,
+                            const void *A, const void *B, double beta, void *C, void *stream);
+
+/*
  * Synthetic operand generator on the device: element k (packed order) =
  * uniform[-1,1) from splitmix64(seed + first + k), bit-identical to the CPU
  * oracle's generator.  No reference counterpart.
