@@ -130,6 +130,36 @@ def main():
                               "launches": 1, "ms": round(ms, 4), "TFLOP/s": round(flops / ms * 1e-9, 3),
                               "GB/s": round(nbytes / ms * 1e-6, 1), "flops": flops,
                               "one_launch_per_problem_ms_extrapolated_from_%d" % sub: round(per_launch_ms, 2)}))
+    if "fastr" in what:
+        import numpy as np
+        from ctc_amd import fastr
+        from oracle import fastr as ofastr
+        b = ofastr.make_batch(seed=0xFA57)  # 32 regions x U{1..8} consensuses x U{20..200} reads, read length 100
+        d = fastr.DeviceBatch(b, DEV)
+        ms = time_ms(lambda: d.run(), warmup=3, iters=20)
+        t0 = time.perf_counter()
+        want_score, want_index = ofastr.best_offsets(b, threads=min(16, os.cpu_count() or 1))
+        cpu_s = time.perf_counter() - t0
+        score, index = d.results()
+        exact = bool(np.array_equal(score, want_score) and np.array_equal(index, want_index))
+        # work: every (pair, offset, read base) byte compare of a full scan
+        compares = 0
+        cons = 0
+        read_off = 0
+        for t in range(len(b["n_consensus"])):
+            rl = b["read_len"][read_off:read_off + b["alt_reads"][t]].astype(np.int64)
+            for _k in range(b["n_consensus"][t]):
+                L = int(b["ref_lens"][cons])
+                compares += int(((np.maximum(L - rl, 0) + 1) * rl).sum())
+                cons += 1
+            read_off += b["alt_reads"][t]
+        in_bytes = b["ref"].size + b["read_seq"].size + b["quals"].size + 8 * b["read_len"].size + 8 * d.n_pairs
+        print(json.dumps({"workload": "config5(ii) FASTR scoring batch: 32 regions, %d (read, consensus) pairs" % d.n_pairs,
+                          "ms": round(ms, 4), "pairs/s": round(d.n_pairs / ms * 1e3), "bit_exact_vs_oracle": exact,
+                          "full_scan_byte_compares": compares,
+                          "full_scan_Gcompare/s": round(compares / ms * 1e-6, 1),
+                          "bytes_moved": int(in_bytes), "GB/s": round(in_bytes / ms * 1e-6, 2),
+                          "cpu_oracle_s": round(cpu_s, 3), "cpu_threads": min(16, os.cpu_count() or 1)}))
     if "ttgt" in what:
         n = 64
         contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "f64", "ccsd fp64 extent 64", ttgt=True)

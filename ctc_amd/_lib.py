@@ -18,6 +18,8 @@ SYMBOLS = (
     "ctc_tc_ttgt_workspace_bytes", "ctc_tc_execute_ttgt", "ctc_tc_fill", "ctc_tc_time_execute",
     "ctc_tc_grouped_contract",
 )
+# every symbol include/ctc_fastr.h declares
+FASTR_SYMBOLS = ("ctc_fastr_best_offsets",)
 
 F64, F32, BF16 = 0, 1, 2
 

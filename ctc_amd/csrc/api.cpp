@@ -31,6 +31,15 @@ int fail_hip(hipError_t e, const char *what)
     return fail(CTC_TC_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+}  // namespace
+
+namespace ctc_internal {
+// shared with the other translation units of the library
+int set_last_error(int code, const std::string &msg) { return fail(code, msg); }
+}  // namespace ctc_internal
+
+namespace {
+
 // offset tables of one plan resident on one device
 struct DeviceTables {
     int64_t *base = nullptr;

@@ -61,6 +61,26 @@ struct SmallGemm {
 hipError_t launch_grouped(int dtype, const SmallGemm *problems_device, int count, const void *A, const void *B,
                           void *C, double alpha, double beta, hipStream_t stream);
 
+// FASTR scoring: one work item = one consensus x up to fastr_reads_per_block() reads.
+struct FastrWork {
+    int64_t ref_off;     // first byte of the consensus in ref
+    int32_t ref_len;
+    int32_t n_reads;     // reads handled by this workgroup
+    int64_t first_read;  // global index of its first read
+    int64_t score_off;   // index of its first result
+};
+struct FastrParams {
+    const unsigned char *ref = nullptr, *read_seq = nullptr, *quals = nullptr;
+    const int32_t *read_len = nullptr, *original_alignment = nullptr;
+    const FastrWork *work = nullptr;
+    int32_t *best_score = nullptr, *best_index = nullptr;
+    int read_stride = 0;
+};
+int fastr_max_ref_lds();
+int fastr_max_read_lds();
+int fastr_reads_per_block();
+hipError_t launch_fastr(const FastrParams &p, int n_blocks, bool staged, hipStream_t stream);
+
 // Generic tiled permutation through element-offset tables (see permute_kernels.hip).
 struct PermuteParams {
     const void *in = nullptr;

@@ -25,3 +25,29 @@ for prog in execute_engine query_engine; do
 done
 rm -rf "$OUT/obj"
 echo "built $OUT/execute_engine $OUT/query_engine"
+
+#   libfastr_ref.so : the reference's CPU scoring path of apps/fastr (findBestOffset and
+#       mismatchQualitySumIgnoreCigar), compiled from the reference sources with the vendored
+#       bamtools API, wrapped by oracle/fastr_ref_harness.cpp.  Needs zlib, pthread and an
+#       OpenCL loader to link (the OpenCL code is never executed).
+F=$REF/apps/fastr
+if [ -d "$F" ]; then
+    mkdir -p "$OUT/fobj"
+    FXX="g++ -std=gnu++98 -O1 -w -fpermissive -fPIC -I$F -I$F/bamtools/src"
+    objs=""
+    for f in AlignedRead BamRegionData Consensus ConsensusHashTable Fasta GenomeLoc HelperFunctions ReadBin \
+             SWPairwiseAlignment SortedBamWriter disorder oclHelper split; do
+        $FXX -c "$F/$f.cpp" -o "$OUT/fobj/$f.o" &
+        objs="$objs $OUT/fobj/$f.o"
+    done
+    for f in "$F"/bamtools/src/api/*.cpp "$F"/bamtools/src/api/internal/*.cpp; do
+        o="$OUT/fobj/bt_$(basename "$f" .cpp).o"
+        $FXX -c "$f" -o "$o" &
+        objs="$objs $o"
+    done
+    $FXX -c "$HERE/fastr_ref_harness.cpp" -o "$OUT/fobj/harness.o" &
+    wait
+    g++ -shared -o "$OUT/libfastr_ref.so" "$OUT/fobj/harness.o" $objs -lz -lpthread -lOpenCL
+    rm -rf "$OUT/fobj"
+    echo "built $OUT/libfastr_ref.so"
+fi

@@ -8,19 +8,20 @@ from ctc_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ctc_tc.h")).read()
+def _declared_symbols(header="ctc_tc.h", prefix="ctc_tc_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ctc_tc_[a-z_0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(%s[a-z_0-9]+)\s*\(" % prefix, text)))
 
 
 def test_header_and_binding_agree():
     assert _declared_symbols() == sorted(_lib.SYMBOLS)
+    assert _declared_symbols("ctc_fastr.h", "ctc_fastr_") == sorted(_lib.FASTR_SYMBOLS)
 
 
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
-    for name in _declared_symbols():
+    for name in _declared_symbols() + _declared_symbols("ctc_fastr.h", "ctc_fastr_"):
         assert hasattr(lib, name), name
 
 
@@ -34,6 +35,6 @@ def test_version_and_error_string():
 
 
 def test_signatures_are_plain_c():
-    text = open(os.path.join(ROOT, "include", "ctc_tc.h")).read()
+    text = open(os.path.join(ROOT, "include", "ctc_tc.h")).read() + open(os.path.join(ROOT, "include", "ctc_fastr.h")).read()
     assert "torch" not in text and "at::" not in text and "std::" not in text
     assert 'extern "C"' in text

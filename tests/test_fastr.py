@@ -1,0 +1,145 @@
+"""FASTR read-vs-consensus scoring (the one path with a TRUE reference oracle).
+
+not gpu:  the C restatement (oracle/fastr_ref.c) against vectors produced by the reference's own
+          findBestOffset (tests/golden/fastr_golden.json, made by oracle/make_fastr_golden.py from
+          oracle/_ref/libfastr_ref.so) and, when that library is present, against it live.
+gpu:      the HIP kernel through ctc_fastr_best_offsets against the same vectors and against the
+          oracle on seeded batches; integer results must be bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fastr as ofastr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(ROOT, "tests", "golden", "fastr_golden.json")) as f:
+        return json.load(f)
+
+
+def _golden_batch(gold):
+    b = gold["batch"]
+    return {
+        "ref": np.frombuffer(b["ref"].encode(), dtype=np.uint8).copy(),
+        "read_seq": np.frombuffer(b["read_seq"].encode(), dtype=np.uint8).copy(),
+        "quals": np.array(b["quals"], dtype=np.uint8),
+        "read_len": np.array(b["read_len"], dtype=np.int32),
+        "original_alignment": np.array(b["original_alignment"], dtype=np.int32),
+        "n_consensus": np.array(b["n_consensus"], dtype=np.int32),
+        "alt_reads": np.array(b["alt_reads"], dtype=np.int32),
+        "ref_lens": np.array(b["ref_lens"], dtype=np.int32),
+        "read_stride": b["read_stride"],
+    }
+
+
+def _case_batch(case):
+    """A one-region, one-consensus, one-read batch from a hand case."""
+    read = np.frombuffer(case["read"].encode(), dtype=np.uint8)
+    return {
+        "ref": np.frombuffer(case["ref"].encode(), dtype=np.uint8).copy(),
+        "read_seq": read.copy(), "quals": np.array(case["quals"], dtype=np.uint8),
+        "read_len": np.array([len(read)], dtype=np.int32),
+        "original_alignment": np.array([case["original_alignment"]], dtype=np.int32),
+        "n_consensus": np.array([1], dtype=np.int32), "alt_reads": np.array([1], dtype=np.int32),
+        "ref_lens": np.array([len(case["ref"])], dtype=np.int32), "read_stride": len(read),
+    }
+
+
+def test_oracle_matches_reference_vectors_hand_cases(gold):
+    for c in gold["cases"]:
+        got = ofastr.find_best_offset(np.frombuffer(c["ref"].encode(), np.uint8), np.frombuffer(c["read"].encode(), np.uint8),
+                                      np.array(c["quals"], np.uint8), c["original_alignment"])
+        assert got == (c["best_index"], c["best_score"]), c["name"]
+
+
+def test_oracle_matches_reference_vectors_batch(gold):
+    score, index = ofastr.best_offsets(_golden_batch(gold), threads=2)
+    assert score.tolist() == gold["batch"]["best_score"]
+    assert index.tolist() == gold["batch"]["best_index"]
+
+
+def test_generator_reproduces_the_committed_batch(gold):
+    g = gold["batch"]["generator"]
+    b = ofastr.make_batch(seed=g["seed"], n_regions=g["n_regions"], max_consensus=g["max_consensus"],
+                          reads=tuple(g["reads"]), read_len=g["read_len"], ref_len=tuple(g["ref_len"]))
+    want = _golden_batch(gold)
+    for k in ("ref", "read_seq", "quals", "read_len", "original_alignment", "n_consensus", "alt_reads", "ref_lens"):
+        assert np.array_equal(b[k], want[k]), k
+
+
+@pytest.mark.skipif(not ofastr.reference_available(), reason="oracle/_ref/libfastr_ref.so not built")
+def test_oracle_matches_reference_live_on_a_fresh_batch():
+    b = ofastr.make_batch(seed=0xBEEF, n_regions=3, max_consensus=5, reads=(8, 20), read_len=50, ref_len=(120, 400))
+    score, index = ofastr.best_offsets(b)
+    for j, (r, rd, q, o) in enumerate(ofastr.pair_iter(b)):
+        assert ofastr.reference_find_best_offset(r, rd, q, o) == (int(index[j]), int(score[j])), j
+
+
+def test_empty_regions_and_ragged_batches():
+    b = ofastr.make_batch(seed=3, n_regions=4, max_consensus=3, reads=(1, 5), read_len=20, ref_len=(40, 80))
+    b["alt_reads"][1] = 0  # a region without reads contributes no pairs
+    keep = np.ones(len(b["read_len"]), dtype=bool)
+    # drop that region's reads from the flattened arrays
+    first = int(ofastr.make_batch(seed=3, n_regions=4, max_consensus=3, reads=(1, 5), read_len=20, ref_len=(40, 80))["alt_reads"][0])
+    n1 = int(ofastr.make_batch(seed=3, n_regions=4, max_consensus=3, reads=(1, 5), read_len=20, ref_len=(40, 80))["alt_reads"][1])
+    keep[first:first + n1] = False
+    b["read_len"], b["original_alignment"] = b["read_len"][keep], b["original_alignment"][keep]
+    rs = b["read_stride"]
+    b["read_seq"] = b["read_seq"].reshape(-1, rs)[keep].reshape(-1)
+    b["quals"] = b["quals"].reshape(-1, rs)[keep].reshape(-1)
+    score, index = ofastr.best_offsets(b)
+    assert score.size == int(np.dot(b["n_consensus"], b["alt_reads"]))
+
+
+# ---------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+def test_gpu_hand_cases_match_reference_vectors(cuda, gold):
+    from ctc_amd import fastr
+    for c in gold["cases"]:
+        score, index = fastr.best_offsets(_case_batch(c), cuda)
+        assert (int(index[0]), int(score[0])) == (c["best_index"], c["best_score"]), c["name"]
+
+
+@pytest.mark.gpu
+def test_gpu_batch_matches_reference_vectors(cuda, gold):
+    from ctc_amd import fastr
+    score, index = fastr.best_offsets(_golden_batch(gold), cuda)
+    assert score.tolist() == gold["batch"]["best_score"]
+    assert index.tolist() == gold["batch"]["best_index"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [
+    dict(seed=0xFA57),                                                           # the benchmark batch: 32 regions
+    dict(seed=11, n_regions=5, read_len=150, ref_len=(200, 600)),                # reads longer than the reference's 100-byte slot
+    dict(seed=12, n_regions=3, read_len=33, ref_len=(40, 90), read_stride=48),   # slots wider than the reads
+    dict(seed=13, n_regions=2, max_consensus=2, reads=(3, 9), read_len=100, ref_len=(9000, 9500)),  # beyond the LDS budget
+    dict(seed=14, n_regions=6, reads=(1, 3), read_len=8, ref_len=(8, 12), with_n=False),            # tiny
+    dict(seed=15, n_regions=4, mismatch_pct=30),                                 # noisy reads: bounds rarely help
+])
+def test_gpu_matches_oracle_on_seeded_batches(cuda, kw):
+    from ctc_amd import fastr
+    b = ofastr.make_batch(**kw)
+    want_score, want_index = ofastr.best_offsets(b)
+    score, index = fastr.best_offsets(b, cuda)
+    assert np.array_equal(score, want_score)
+    assert np.array_equal(index, want_index)
+
+
+@pytest.mark.gpu
+def test_gpu_empty_batch(cuda):
+    import torch
+    from ctc_amd import fastr
+    b = ofastr.make_batch(seed=1, n_regions=2, reads=(2, 3), read_len=10, ref_len=(40, 60))
+    d = fastr.DeviceBatch(b, cuda)
+    d.n_consensus[:] = 0
+    d.best_score.fill_(-7)
+    d.run()
+    torch.cuda.synchronize()
+    assert int(d.best_score[0]) == -7
