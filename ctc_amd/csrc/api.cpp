@@ -46,6 +46,13 @@ struct DeviceTables {
     const int64_t *row_a = nullptr, *k_a = nullptr, *k_b = nullptr, *col_b = nullptr;
     const int64_t *row_c = nullptr, *col_c = nullptr, *bat_a = nullptr, *bat_b = nullptr, *bat_c = nullptr;
     const int64_t *sk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // bx cx by cy bo co
+    // split-K workspace of this plan on this device: grows on demand; executions on different
+    // streams are ordered through ws_done so that they never share it concurrently
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    hipEvent_t ws_done = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_used = false;
 };
 
 struct PermuteTables {
@@ -189,6 +196,27 @@ template <typename V> int64_t copy_out(const V &v, int64_t *out, int64_t cap)
     return n;
 }
 
+// caller holds the plan's mutex
+int grow_workspace(DeviceTables &dt, size_t bytes)
+{
+    if (dt.ws_bytes < bytes) {
+        if (dt.ws) {
+            (void)hipDeviceSynchronize();  // nobody may still be using the old workspace
+            (void)hipFree(dt.ws);
+            dt.ws = nullptr;
+            dt.ws_bytes = 0;
+        }
+        hipError_t e = hipMalloc(&dt.ws, bytes);
+        if (e != hipSuccess) return fail_hip(e, "hipMalloc(split-K workspace)");
+        dt.ws_bytes = bytes;
+    }
+    if (!dt.ws_done) {
+        hipError_t e = hipEventCreateWithFlags(&dt.ws_done, hipEventDisableTiming);
+        if (e != hipSuccess) return fail_hip(e, "hipEventCreate");
+    }
+    return CTC_TC_OK;
+}
+
 int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, double beta, void *C,
                 hipStream_t stream)
 {
@@ -242,7 +270,28 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     if (la != ctc::kLayoutScalar && (reinterpret_cast<uintptr_t>(g.A) & 15)) la = ctc::kLayoutScalar;
     if (lb != ctc::kLayoutScalar && (reinterpret_cast<uintptr_t>(g.B) & 15)) lb = ctc::kLayoutScalar;
 
-    hipError_t e = ctc::launch_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, stream);
+    ctc::GemmSchedule sch;
+    hipError_t e = ctc::schedule_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, &sch);
+    if (e != hipSuccess) return fail_hip(e, "contraction schedule");
+    void *ws = nullptr;
+    if (sch.ws_bytes > 0) {
+        std::lock_guard<std::mutex> lock(pl->mu);
+        DeviceTables &dt = pl->tables[device];
+        if (dt.ws_used && dt.ws_stream != stream) {
+            e = hipStreamWaitEvent(stream, dt.ws_done, 0);
+            if (e != hipSuccess) return fail_hip(e, "hipStreamWaitEvent");
+        }
+        int wrc = grow_workspace(dt, sch.ws_bytes);
+        if (wrc) return wrc;
+        ws = dt.ws;
+        e = ctc::launch_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, sch, ws, stream);
+        if (e != hipSuccess) return fail_hip(e, "contraction kernel launch");
+        (void)hipEventRecord(dt.ws_done, stream);
+        dt.ws_stream = stream;
+        dt.ws_used = true;
+        return CTC_TC_OK;
+    }
+    e = ctc::launch_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, sch, nullptr, stream);
     if (e != hipSuccess) return fail_hip(e, "contraction kernel launch");
     return CTC_TC_OK;
 }
@@ -280,11 +329,15 @@ int ctc_tc_plan_create(const char *spec, int n_ext, const char *mode_names, cons
 int ctc_tc_plan_destroy(ctc_tc_plan *plan)
 {
     if (!plan) return CTC_TC_OK;
-    for (auto &kv : plan->tables)
-        if (kv.second.base) (void)hipFree(kv.second.base);
-    if (plan->packed)
-        for (auto &kv : plan->packed->tables)
+    auto release = [](std::map<int, DeviceTables> &tables) {
+        for (auto &kv : tables) {
             if (kv.second.base) (void)hipFree(kv.second.base);
+            if (kv.second.ws) (void)hipFree(kv.second.ws);
+            if (kv.second.ws_done) (void)hipEventDestroy(kv.second.ws_done);
+        }
+    };
+    release(plan->tables);
+    if (plan->packed) release(plan->packed->tables);
     delete plan;
     return CTC_TC_OK;
 }
@@ -364,7 +417,22 @@ int ctc_tc_plan_prepare(ctc_tc_plan *plan)
     int rc = current_device(device);
     if (rc) return rc;
     DeviceTables t;
-    return upload_tables(plan, device, t);
+    rc = upload_tables(plan, device, t);
+    if (rc) return rc;
+    const ctc::Plan &p = plan->plan;
+    if (p.kernel == ctc::kKernelGemm && p.dtype != ctc::kBF16 && p.batch <= 65535) {
+        // the split-K workspace the vector-load variant will ask for
+        ctc::GemmParams g;
+        g.M = p.M; g.N = p.N; g.K = p.K;
+        g.batch = (int)p.batch;
+        ctc::GemmSchedule sch;
+        if (ctc::schedule_gemm(p.dtype, p.layout_a, p.layout_b, p.tile.bm, p.tile.bn, g, &sch) == hipSuccess &&
+            sch.ws_bytes > 0) {
+            std::lock_guard<std::mutex> lock(plan->mu);
+            rc = grow_workspace(plan->tables[device], sch.ws_bytes);
+        }
+    }
+    return rc;
 }
 
 int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta, void *C,

@@ -185,12 +185,24 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     // Block -> tile.  Blocks b and b+8 share an XCD (and its L2): give each XCD a
     // contiguous run of tile ids, then walk tiles in groups of `group` tile rows so
     // that concurrently running blocks share A and B panels.
-    const int nblk = p.nbm * p.nbn;
-    int sid;
+    // The first dp_tiles tiles run whole (one workgroup each).  The remaining tiles - the
+    // last, partly filled round of the grid - are cut along K into `split` chunks so that
+    // they occupy every workgroup slot for 1/split of a tile's time; a chunk's raw
+    // accumulators go to a workspace and splitk_fixup_kernel sums them in chunk order.
+    int sid, chunk = 0;
+    bool partial = false;
     {
         const int bid = blockIdx.x;
-        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if (bid < p.dp_tiles) {
+            const int nblk = p.dp_tiles;
+            const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+            sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        } else {
+            const int item = bid - p.dp_tiles;
+            sid = p.dp_tiles + item / p.split;
+            chunk = item % p.split;
+            partial = true;
+        }
     }
     const int width = p.group * p.nbn;
     const int first_m = (sid / width) * p.group;
@@ -216,7 +228,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = zero_of<acc_t>();
 
-    const int nk = (int)((p.K + BK - 1) / BK);
+    const int nk_total = (int)((p.K + BK - 1) / BK);
+    const int kt_first = partial ? (int)((int64_t)chunk * nk_total / p.split) : 0;
+    const int kt_last = partial ? (int)((int64_t)(chunk + 1) * nk_total / p.split) : nk_total;
+    const int nk = kt_last - kt_first;
+    const int64_t k_base = (int64_t)kt_first * BK;
     constexpr int KSTEPS = BK / 4;
     static_assert(KSTEPS % 2 == 0, "fragment slots alternate per k-step");
     const int frow = lane & 15;
@@ -224,25 +240,25 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
 
     // Prologue: tile 0 into LDS buffer 0, tile 1 on its way in registers, first
     // fragments of tile 0 in registers.
-    sa.fetch_step(p.k_a, 0);
-    sb.fetch_step(p.k_b, 0);
+    sa.fetch_step(p.k_a, k_base);
+    sb.fetch_step(p.k_b, k_base);
 #pragma unroll
     for (int i = 0; i < SA::NV; ++i) sa.issue_one(i, A);
 #pragma unroll
     for (int i = 0; i < SB::NV; ++i) sb.issue_one(i, B);
-    sa.fetch_step(p.k_a, BK);
-    sb.fetch_step(p.k_b, BK);
+    sa.fetch_step(p.k_a, k_base + BK);
+    sb.fetch_step(p.k_b, k_base + BK);
 #pragma unroll
-    for (int i = 0; i < SA::NV; ++i) sa.template commit_one<true>(i, smem, 0, p.K);
+    for (int i = 0; i < SA::NV; ++i) sa.template commit_one<true>(i, smem, k_base, p.K);
 #pragma unroll
-    for (int i = 0; i < SB::NV; ++i) sb.template commit_one<true>(i, smem + SA::LDS_ELEMS, 0, p.K);
+    for (int i = 0; i < SB::NV; ++i) sb.template commit_one<true>(i, smem + SA::LDS_ELEMS, k_base, p.K);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < SA::NV; ++i) sa.issue_one(i, A);
 #pragma unroll
     for (int i = 0; i < SB::NV; ++i) sb.issue_one(i, B);
-    sa.fetch_step(p.k_a, 2 * (int64_t)BK);
-    sb.fetch_step(p.k_b, 2 * (int64_t)BK);
+    sa.fetch_step(p.k_a, k_base + 2 * (int64_t)BK);
+    sb.fetch_step(p.k_b, k_base + 2 * (int64_t)BK);
 
     T fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -273,7 +289,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
         const T *lb = la + SA::LDS_ELEMS;
         T *na = smem + (cur ^ 1) * STAGE_ELEMS;
         T *nb = na + SA::LDS_ELEMS;
-        const int64_t k_next = (int64_t)(kt + 1) * BK;
+        const int64_t k_next = k_base + (int64_t)(kt + 1) * BK;
 #ifdef CTC_STAMPS
         unsigned long long t0, t1, t2, t3;
         CTC_STAMP(t0);
@@ -329,8 +345,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
                     }
                 }
                 if (do_issue && q == NMFMA - 1) {
-                    sa.fetch_step(p.k_a, (int64_t)(kt + 3) * BK);
-                    sb.fetch_step(p.k_b, (int64_t)(kt + 3) * BK);
+                    sa.fetch_step(p.k_a, k_base + (int64_t)(kt + 3) * BK);
+                    sb.fetch_step(p.k_b, k_base + (int64_t)(kt + 3) * BK);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -361,6 +377,19 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     // Epilogue: lanes 0..15 of each quarter-wave hold 16 consecutive N positions of
     // one row, so every store instruction writes four contiguous runs of C.  The
     // beta test is hoisted so the common beta == 0 path is a straight run of stores.
+    if (partial) {
+        // raw accumulators of this K chunk: tile-shaped slab [BM][BN] in the workspace
+        T *slab = static_cast<T *>(p.ws) + ((int64_t)(sid - p.dp_tiles) * p.split + chunk) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm0 + 16 * i + Tr::acc_row(lane, r);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) slab[row * BN + wn0 + 16 * j + frow] = acc[i][j][r];
+            }
+        return;
+    }
     const T alpha = (T)p.alpha, beta = (T)p.beta;
     int64_t coff[TN];
     bool cok[TN];
@@ -412,19 +441,124 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
 #endif
 }
 
+// Sums the K chunks of the split tiles in chunk order and writes C = alpha * sum + beta * C.
+// One workgroup per (tile, 16 rows); a thread owns two neighbouring columns.
+template <typename T, int BM, int BN>
+__global__ void __launch_bounds__(256) splitk_fixup_kernel(const GemmParams p)
+{
+    constexpr int ROWS = 16, VPR = BN / 2, RPP = 256 / VPR;  // vectors per row, rows per pass
+    const int tile_rel = blockIdx.x / (BM / ROWS);
+    const int rblk = blockIdx.x % (BM / ROWS);
+    const int sid = p.dp_tiles + tile_rel;
+    const int width = p.group * p.nbn;
+    const int first_m = (sid / width) * p.group;
+    const int gsz = min(p.nbm - first_m, p.group);
+    const int tm = first_m + (sid % width) % gsz;
+    const int tn = (sid % width) / gsz;
+    const T *slab0 = static_cast<const T *>(p.ws) + (int64_t)tile_rel * p.split * (BM * BN);
+    T *C = static_cast<T *>(p.C);
+    const T alpha = (T)p.alpha, beta = (T)p.beta;
+    const int cv = threadIdx.x % VPR;
+    const int64_t n = (int64_t)tn * BN + 2 * cv;
+    const bool ok0 = n < p.N, ok1 = n + 1 < p.N;
+    const int64_t c0 = p.col_c[ok0 ? n : 0], c1 = p.col_c[ok1 ? n + 1 : 0];
+    for (int rr = threadIdx.x / VPR; rr < ROWS; rr += RPP) {
+        const int row = rblk * ROWS + rr;
+        const int64_t m = (int64_t)tm * BM + row;
+        if (m >= p.M) continue;
+        T s0 = 0, s1 = 0;
+        for (int c = 0; c < p.split; ++c) {
+            const T *src = slab0 + (int64_t)c * (BM * BN) + row * BN + 2 * cv;
+            s0 += src[0];
+            s1 += src[1];
+        }
+        const int64_t ro = p.row_c[m];
+        if (ok0) {
+            T v = alpha * s0;
+            if (beta != (T)0) v += beta * C[ro + c0];
+            C[ro + c0] = v;
+        }
+        if (ok1) {
+            T v = alpha * s1;
+            if (beta != (T)0) v += beta * C[ro + c1];
+            C[ro + c1] = v;
+        }
+    }
+}
+
+// workgroup slots of the current device for one kernel instantiation (cached per device)
+template <typename K> int resident_slots(K kernel, int threads)
+{
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cache[dev] == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) return 0;
+        cache[dev] = cus * per_cu > 0 ? cus * per_cu : -1;
+    }
+    return cache[dev] > 0 ? cache[dev] : 0;
+}
+
+// Splits the tiles of the last, partly filled round along K.  tiles = q * slots + tail:
+// the q full rounds stay data-parallel; each tail tile is cut into floor(slots / tail)
+// chunks (at least kMinChunkTiles K-tiles each) so the tail finishes in 1/split of a round.
+constexpr int kMinChunkTiles = 8;
+
 template <typename T, int LA, int LB, int BM, int BN>
-hipError_t launch_one(const GemmParams &p, hipStream_t stream)
+hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
+{
+    constexpr int BK = 16, WM = 2, WN = 2;
+    GemmSchedule s;
+    s.nbm = (int)((p.M + BM - 1) / BM);
+    s.nbn = (int)((p.N + BN - 1) / BN);
+    const int64_t tiles = (int64_t)s.nbm * s.nbn;
+    if (tiles > 0x7FFFFFFF) return hipErrorInvalidValue;
+    s.dp_tiles = (int)tiles;
+    s.split = 1;
+    s.tail_tiles = 0;
+    s.ws_bytes = 0;
+    static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
+    const int slots = resident_slots(gemm_kernel<T, LA, LB, BM, BN, BK, WM, WN>, 64 * WM * WN);
+    const int nk = (int)((p.K + BK - 1) / BK);
+    if (!no_split && slots > 0 && p.batch == 1) {
+        const int tail = (int)(tiles % slots);
+        if (tail > 0) {
+            int f = slots / tail;
+            if (f > nk / kMinChunkTiles) f = nk / kMinChunkTiles;
+            if (f >= 2) {
+                s.tail_tiles = tail;
+                s.dp_tiles = (int)tiles - tail;
+                s.split = f;
+                s.ws_bytes = (size_t)tail * f * BM * BN * sizeof(T);
+            }
+        }
+    }
+    *out = s;
+    return hipSuccess;
+}
+
+template <typename T, int LA, int LB, int BM, int BN>
+hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     constexpr int BK = 16, WM = 2, WN = 2;
     GemmParams q = p;
-    q.nbm = (int)((p.M + BM - 1) / BM);
-    q.nbn = (int)((p.N + BN - 1) / BN);
+    q.nbm = sch.nbm;
+    q.nbn = sch.nbn;
+    q.dp_tiles = sch.dp_tiles;
+    q.split = sch.split;
+    q.ws = ws;
     if (q.group < 1) q.group = 1;
-    dim3 grid((unsigned)(q.nbm * q.nbn), (unsigned)p.batch, 1);
+    if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
+    dim3 grid((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1);
     dim3 block(64 * WM * WN, 1, 1);
     // diagnostic knob: extra dynamic LDS per block lowers the number of co-resident blocks per CU
     static const size_t extra_lds = getenv("CTC_TC_DEBUG_EXTRA_LDS") ? (size_t)atol(getenv("CTC_TC_DEBUG_EXTRA_LDS")) : 0;
     hipLaunchKernelGGL((gemm_kernel<T, LA, LB, BM, BN, BK, WM, WN>), grid, block, extra_lds, stream, q);
+    if (sch.tail_tiles > 0)
+        hipLaunchKernelGGL((splitk_fixup_kernel<T, BM, BN>), dim3((unsigned)(sch.tail_tiles * (BM / 16))), dim3(256), 0,
+                           stream, q);
 #ifdef CTC_STAMPS
     {
         (void)hipStreamSynchronize(stream);
@@ -440,58 +574,60 @@ hipError_t launch_one(const GemmParams &p, hipStream_t stream)
         for (int b = 0; b < nb; ++b)
             for (int i = 0; i < 3; ++i) ph[i].push_back((double)h[8 * b + 5 + i]);
         for (int i = 0; i < 3; ++i) std::sort(ph[i].begin(), ph[i].end());
-        {
-            std::vector<double> clk;
-            for (int b = 0; b < nb; ++b)
-                clk.push_back((double)(h[8 * b + 5] + h[8 * b + 6] + h[8 * b + 7]) / (double)std::max<unsigned long long>(1, h[8 * b + 3]) * 100.0);
-            std::sort(clk.begin(), clk.end());
-            fprintf(stderr, "[stamps] shader clock MHz (min/median/max over blocks): %.0f / %.0f / %.0f\n", clk[0], clk[nb / 2], clk[nb - 1]);
-        }
         fprintf(stderr, "[stamps] per block ticks (median/max): prologue %.0f/%.0f | loop %.0f/%.0f | epilogue %.0f/%.0f\n",
                 ph[0][nb / 2], ph[0][nb - 1], ph[1][nb / 2], ph[1][nb - 1], ph[2][nb / 2], ph[2][nb - 1]);
-        fprintf(stderr, "[stamps] per K-tile ticks (median over %d blocks): ksteps0..n-3 %.0f | commit kstep %.0f | barrier %.0f | issue kstep %.0f | total %.0f\n",
-                nb, med[0], med[1], med[2], med[3], med[0] + med[1] + med[2] + med[3]);
+        fprintf(stderr, "[stamps] per K-tile ticks (median over %d blocks): ksteps0..n-3 %.0f | commit kstep %.0f | barrier %.0f | realtime %.0f\n",
+                nb, med[0], med[1], med[2], med[3]);
     }
 #endif
     return hipGetLastError();
 }
 
 template <typename T, int BM, int BN>
-hipError_t launch_layouts(int la, int lb, const GemmParams &p, hipStream_t stream)
+hipError_t dispatch_layouts(int la, int lb, const GemmParams &p, GemmSchedule *sch_out, const GemmSchedule *sch_in,
+                            void *ws, hipStream_t stream)
 {
+#define CTC_CASE(A_, B_)                                                                                      \
+    case A_ * 3 + B_:                                                                                          \
+        return sch_out ? schedule_one<T, A_, B_, BM, BN>(p, sch_out) : launch_one<T, A_, B_, BM, BN>(p, *sch_in, ws, stream);
     switch (la * 3 + lb) {
-    case 0: return launch_one<T, 0, 0, BM, BN>(p, stream);
-    case 1: return launch_one<T, 0, 1, BM, BN>(p, stream);
-    case 2: return launch_one<T, 0, 2, BM, BN>(p, stream);
-    case 3: return launch_one<T, 1, 0, BM, BN>(p, stream);
-    case 4: return launch_one<T, 1, 1, BM, BN>(p, stream);
-    case 5: return launch_one<T, 1, 2, BM, BN>(p, stream);
-    case 6: return launch_one<T, 2, 0, BM, BN>(p, stream);
-    case 7: return launch_one<T, 2, 1, BM, BN>(p, stream);
-    case 8: return launch_one<T, 2, 2, BM, BN>(p, stream);
+        CTC_CASE(0, 0) CTC_CASE(0, 1) CTC_CASE(0, 2) CTC_CASE(1, 0) CTC_CASE(1, 1) CTC_CASE(1, 2)
+        CTC_CASE(2, 0) CTC_CASE(2, 1) CTC_CASE(2, 2)
     default: return hipErrorInvalidValue;
     }
+#undef CTC_CASE
 }
 
 template <typename T>
-hipError_t launch_tiles(int la, int lb, int bm, int bn, const GemmParams &p, hipStream_t stream)
+hipError_t dispatch_tiles(int la, int lb, int bm, int bn, const GemmParams &p, GemmSchedule *sch_out,
+                          const GemmSchedule *sch_in, void *ws, hipStream_t stream)
 {
-    if (bm == 128 && bn == 128) return launch_layouts<T, 128, 128>(la, lb, p, stream);
-    if (bm == 64 && bn == 64) return launch_layouts<T, 64, 64>(la, lb, p, stream);
+    if (bm == 128 && bn == 128) return dispatch_layouts<T, 128, 128>(la, lb, p, sch_out, sch_in, ws, stream);
+    if (bm == 64 && bn == 64) return dispatch_layouts<T, 64, 64>(la, lb, p, sch_out, sch_in, ws, stream);
+    return hipErrorInvalidValue;
+}
+
+hipError_t dispatch(int dtype, int la, int lb, int bm, int bn, const GemmParams &p, GemmSchedule *sch_out,
+                    const GemmSchedule *sch_in, void *ws, hipStream_t stream)
+{
+    if (la < 0 || la > 2 || lb < 0 || lb > 2) return hipErrorInvalidValue;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
+    if (dtype == 0) return dispatch_tiles<double>(la, lb, bm, bn, p, sch_out, sch_in, ws, stream);
+    if (dtype == 1) return dispatch_tiles<float>(la, lb, bm, bn, p, sch_out, sch_in, ws, stream);
     return hipErrorInvalidValue;
 }
 
 }  // namespace
 
-hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
-                       hipStream_t stream)
+hipError_t schedule_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p, GemmSchedule *out)
 {
-    if (layout_a < 0 || layout_a > 2 || layout_b < 0 || layout_b > 2) return hipErrorInvalidValue;
-    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0) return hipErrorInvalidValue;
-    if (p.batch > 65535) return hipErrorInvalidValue;
-    if (dtype == 0) return launch_tiles<double>(layout_a, layout_b, bm, bn, p, stream);
-    if (dtype == 1) return launch_tiles<float>(layout_a, layout_b, bm, bn, p, stream);
-    return hipErrorInvalidValue;
+    return dispatch(dtype, layout_a, layout_b, bm, bn, p, out, nullptr, nullptr, nullptr);
+}
+
+hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
+                       const GemmSchedule &schedule, void *workspace, hipStream_t stream)
+{
+    return dispatch(dtype, layout_a, layout_b, bm, bn, p, nullptr, &schedule, workspace, stream);
 }
 
 }  // namespace ctc

@@ -26,13 +26,25 @@ struct GemmParams {
     int batch = 1;
     double alpha = 1.0, beta = 0.0;
     int nbm = 0, nbn = 0, group = 8;
+    // schedule (filled by launch_gemm): tiles [0, dp_tiles) run whole, every later tile is cut
+    // into `split` K chunks whose raw accumulators go to `ws`
+    int dp_tiles = 0, split = 1;
+    void *ws = nullptr;
+};
+
+struct GemmSchedule {
+    int nbm = 0, nbn = 0;
+    int dp_tiles = 0, tail_tiles = 0, split = 1;
+    size_t ws_bytes = 0;  // workspace the launch needs (0: none)
 };
 
 // dtype: 0 f64, 1 f32.  layouts: see ctc_tc_layout.  bm/bn select the tile.
 // Returns hipSuccess or the launch error; hipErrorInvalidValue for an
 // unsupported combination.
+hipError_t schedule_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
+                         GemmSchedule *out);
 hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
-                       hipStream_t stream);
+                       const GemmSchedule &schedule, void *workspace, hipStream_t stream);
 
 // Skinny contraction C(m,n) = sum_k A(m,k) B(k,n) for M <= 16: streams B once and C once.
 // transpose == 0: n is the fused N index, B(k,n) = B[k_b[k] + nb[n]], C(m,n) = C[row_c[m] + nc[n]]

@@ -69,6 +69,11 @@ CASES = [
     ("ccsd_f32", "aeim,ebmj->abij", dict(a=24, b=24, i=24, j=24, e=24, m=24), "f32"),
     ("ccsd_f32_scalar", "aeim,ebmj->abij", dict(a=6, b=7, i=5, j=9, e=3, m=10), "f32"),
     ("hadamard_batch_only", "ab,ab->ab", dict(a=33, b=20), "f64"),
+    # few tiles, long K: every tile is cut along K and summed by the fix-up kernel
+    ("splitk_small_tiles", "ak,kb->ab", dict(a=256, b=256, k=2048), "f64"),
+    ("splitk_ragged", "ak,kb->ab", dict(a=250, b=201, k=2047), "f64"),
+    ("splitk_f32", "ak,bk->ab", dict(a=192, b=320, k=4096), "f32"),
+    ("splitk_permuted", "aeim,ebmj->abij", dict(a=12, b=12, i=12, j=12, e=40, m=40), "f64"),
     # skinny kernels (M <= 16, long N)
     ("skinny_transpose_ragged", "dkca,bk->abcd", dict(a=36, b=8, c=5, d=44, k=8), "f32"),
     ("skinny_transpose_f64_m3", "dkca,bk->abcd", dict(a=34, b=3, c=7, d=66, k=5), "f64"),
@@ -118,6 +123,22 @@ def test_alpha_beta(cuda, oracle):
     ctc_amd.Plan(spec, ext).execute(dA, dB, dC, alpha=0.75, beta=-1.5)
     want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=0.75, beta=-1.5)
     _check(dC.cpu().numpy(), want, "f64")
+
+
+def test_splitk_alpha_beta_and_repeat(cuda, oracle):
+    spec, ext = "ak,kb->ab", dict(a=250, b=201, k=2047)
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, "f64", cuda)
+    C0 = oracle.fill(n_out, 77)
+    want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=1.5, beta=-0.25)
+    plan = ctc_amd.Plan(spec, ext)
+    plan.prepare()
+    other = torch.cuda.Stream()
+    for stream in (None, other, None):  # same plan from two streams: the workspace hand-over is ordered
+        dC = torch.from_numpy(C0.copy()).to(cuda)
+        torch.cuda.synchronize()
+        plan.execute(dA, dB, dC, alpha=1.5, beta=-0.25, stream=stream)
+        torch.cuda.synchronize()
+        _check(dC.cpu().numpy(), want, "f64")
 
 
 def test_beta_zero_ignores_nan_in_c(cuda, oracle):
