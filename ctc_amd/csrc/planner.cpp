@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <sstream>
 
 namespace ctc {
@@ -118,6 +119,11 @@ void choose_tile(Plan &p)
         t.bm = 128; t.bn = 128;
     } else {
         t.bm = 64; t.bn = 64;
+    }
+    // diagnostic knob for A/B runs
+    if (const char *force = getenv("CTC_TC_FORCE_TILE")) {
+        if (atoi(force) == 64) { t.bm = 64; t.bn = 64; }
+        if (atoi(force) == 128) { t.bm = 128; t.bn = 128; }
     }
     t.bk = 16;
     t.threads = 256;
