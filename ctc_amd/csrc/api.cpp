@@ -264,6 +264,8 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     g.batch = (int)p.batch;
     g.alpha = alpha; g.beta = beta;
     g.group = p.tile.group;
+    // 16-byte stores of C need an aligned base as well
+    g.c_vec = (p.vec_c > 1 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) ? p.vec_c : 1;
 
     // vector loads need 16-byte aligned bases; otherwise fall back to element loads
     int la = p.layout_a, lb = p.layout_b;
@@ -378,7 +380,7 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
     case CTC_TC_Q_GEMM_DIMS: v = {p.M, p.N, p.K, p.batch}; break;
     case CTC_TC_Q_TILE:
         v = {p.tile.bm, p.tile.bn, p.tile.bk, p.tile.threads, p.layout_a, p.layout_b,
-             p.vec_a, p.vec_b, p.tile.group, p.kernel};
+             p.vec_a, p.vec_b, p.tile.group, p.kernel, p.vec_c};
         break;
     case CTC_TC_Q_ROW_A: return copy_out(p.row_a, out, cap);
     case CTC_TC_Q_K_A: return copy_out(p.k_a, out, cap);

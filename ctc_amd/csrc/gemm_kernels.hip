@@ -20,6 +20,7 @@
 // Per K-tile the wave runs its MFMAs back to back and deals every other instruction
 // (fragment reads, LDS writes of the next tile, global loads of the tile after it)
 // out behind them, one barrier per tile; see tile_step below.
+#include "gemm_device.hpp"
 #include "kernels.hpp"
 
 #include <algorithm>
@@ -47,114 +48,7 @@ __device__ unsigned long long g_stamp_sums[8 * 8192];
 #define CTC_STAMP(var) do { } while (0)
 #endif
 
-constexpr int kLayOuterVec = 1, kLayScalar = 2;
-
-template <typename T> struct Traits;
-
-template <> struct Traits<double> {
-    typedef double acc_t __attribute__((ext_vector_type(4)));
-    typedef double vec_t __attribute__((ext_vector_type(2)));
-    static constexpr int VEC = 2;
-    static constexpr int PAD_K = 2;
-    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c)
-    {
-        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    }
-    // accumulator register j of lane `lane` holds row acc_row, column lane & 15
-    static __device__ __forceinline__ int acc_row(int lane, int j) { return (lane >> 4) + 4 * j; }
-};
-
-template <> struct Traits<float> {
-    typedef float acc_t __attribute__((ext_vector_type(4)));
-    typedef float vec_t __attribute__((ext_vector_type(4)));
-    static constexpr int VEC = 4;
-    static constexpr int PAD_K = 4;
-    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c)
-    {
-        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ int acc_row(int lane, int j) { return (lane >> 4) * 4 + j; }
-};
-
-template <typename T, int VEC> struct VecOf { typedef typename Traits<T>::vec_t type; };
-template <typename T> struct VecOf<T, 1> { typedef T type; };
-
-template <typename V> __device__ __forceinline__ V zero_of()
-{
-    V v = {};
-    return v;
-}
-
-// Stages a BR x BK operand tile: global -> registers -> LDS.
-// "line": the dimension enumerated across passes (rows when K-major, k when outer-major);
-// "vector position": the dimension enumerated across neighbouring lanes.
-// Rows past the operand's extent are clamped to its last rows (their products land in
-// C elements that are never stored); only the K tail has to read as zero, and only in
-// the last K-tile, so the steady-state path carries no masking at all.  The k tables
-// are padded by the host with kKTablePad entries so lookups need no clamping.
-template <typename T, int LAY, int BR, int BK, int NT> struct Stager {
-    static constexpr bool KMAJ = (LAY != kLayOuterVec);
-    static constexpr int VEC = (LAY == kLayScalar) ? 1 : Traits<T>::VEC;
-    static constexpr int LDS_STRIDE = KMAJ ? BK + Traits<T>::PAD_K : BR + 16;
-    static constexpr int LDS_ELEMS = KMAJ ? BR * LDS_STRIDE : BK * LDS_STRIDE;
-    static constexpr int VPL = (KMAJ ? BK : BR) / VEC;        // vectors per line
-    static constexpr int LINES_PER_PASS = NT / VPL;
-    static constexpr int LINES = KMAJ ? BR : BK;
-    static constexpr int NV = LINES / LINES_PER_PASS;          // vectors per thread per tile
-    static_assert(NT % VPL == 0 && LINES % LINES_PER_PASS == 0 && NV >= 1, "tile/thread mismatch");
-    typedef typename VecOf<T, VEC>::type vec_t;
-
-    // offsets that stay fixed for the whole block (rows) and per K-tile (k)
-    static constexpr int NFIX = KMAJ ? NV : 1;
-    static constexpr int NSTEP = KMAJ ? 1 : NV;
-    int64_t fix_off[NFIX];
-    int64_t step_off[NSTEP];
-    vec_t regs[NV];
-    int vpos, line0;
-
-    __device__ __forceinline__ void init(const int64_t *__restrict__ tab_rows, int64_t r0, int64_t R, int t)
-    {
-        vpos = t % VPL;
-        line0 = t / VPL;
-#pragma unroll
-        for (int i = 0; i < NFIX; ++i) {
-            const int64_t r = KMAJ ? r0 + line0 + i * LINES_PER_PASS : r0 + (int64_t)vpos * VEC;
-            fix_off[i] = tab_rows[r < R ? r : (R - VEC)];
-        }
-    }
-
-    __device__ __forceinline__ void fetch_step(const int64_t *__restrict__ tab_k, int64_t k0)
-    {
-#pragma unroll
-        for (int i = 0; i < NSTEP; ++i)
-            step_off[i] = tab_k[KMAJ ? k0 + vpos * VEC : k0 + line0 + i * LINES_PER_PASS];
-    }
-
-    __device__ __forceinline__ void issue_one(int i, const T *__restrict__ base)
-    {
-        const int64_t off = fix_off[KMAJ ? i : 0] + step_off[KMAJ ? 0 : i];
-        regs[i] = *reinterpret_cast<const vec_t *>(base + off);
-    }
-
-    // k0: first k of the tile held in regs; MASK_K: that tile crosses K
-    template <bool MASK_K>
-    __device__ __forceinline__ void commit_one(int i, T *__restrict__ lds, int64_t k0, int64_t K)
-    {
-        vec_t v = regs[i];
-        const int line = line0 + i * LINES_PER_PASS;
-        if (MASK_K) {
-            const int64_t k = KMAJ ? k0 + vpos * VEC : k0 + line;
-            if (k >= K) v = zero_of<vec_t>();
-        }
-        *reinterpret_cast<vec_t *>(lds + line * LDS_STRIDE + vpos * VEC) = v;
-    }
-
-    // MFMA operand element for tile row rr (0..BR) and k index kq (0..BK)
-    static __device__ __forceinline__ T frag(const T *__restrict__ lds, int rr, int kq)
-    {
-        return KMAJ ? lds[rr * LDS_STRIDE + kq] : lds[kq * LDS_STRIDE + rr];
-    }
-};
+using namespace gemm_detail;
 
 template <typename T, int LA, int LB, int BM, int BN, int BK, int WM, int WN>
 __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams p)
@@ -169,6 +63,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     typedef Stager<T, LB, BN, BK, NT> SB;
 
     __shared__ __attribute__((aligned(16))) T smem[2 * (SA::LDS_ELEMS + SB::LDS_ELEMS)];
+    // element offsets of the tile's C rows and columns (kNoOffset: outside C), fetched in the
+    // prologue so that the epilogue issues its stores without waiting on any global load
+    __shared__ int64_t s_coff[BM + BN];
+    constexpr int64_t kNoOffset = INT64_MIN;
     constexpr int STAGE_ELEMS = SA::LDS_ELEMS + SB::LDS_ELEMS;
 
     const int t = threadIdx.x;
@@ -231,7 +129,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     const int nk_total = (int)((p.K + BK - 1) / BK);
     const int kt_first = partial ? (int)((int64_t)chunk * nk_total / p.split) : 0;
     const int kt_last = partial ? (int)((int64_t)(chunk + 1) * nk_total / p.split) : nk_total;
+#ifdef CTC_EXP_NOLOOP
+    const int nk = 1;
+#else
     const int nk = kt_last - kt_first;
+#endif
     const int64_t k_base = (int64_t)kt_first * BK;
     constexpr int KSTEPS = BK / 4;
     static_assert(KSTEPS % 2 == 0, "fragment slots alternate per k-step");
@@ -248,15 +150,25 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     for (int i = 0; i < SB::NV; ++i) sb.issue_one(i, B);
     sa.fetch_step(p.k_a, k_base + BK);
     sb.fetch_step(p.k_b, k_base + BK);
+    if (!partial) {
+        for (int idx = t; idx < BM + BN; idx += NT) {
+            const bool is_row = idx < BM;
+            const int64_t g = is_row ? m0 + idx : n0 + (idx - BM);
+            const bool ok = g < (is_row ? p.M : p.N);
+            const int64_t off = (is_row ? p.row_c : p.col_c)[ok ? g : 0];
+            s_coff[idx] = ok ? off : kNoOffset;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < SA::NV; ++i) sa.template commit_one<true>(i, smem, k_base, p.K);
 #pragma unroll
     for (int i = 0; i < SB::NV; ++i) sb.template commit_one<true>(i, smem + SA::LDS_ELEMS, k_base, p.K);
-    __syncthreads();
+    // tile 1 leaves for the registers before the barrier: its latency overlaps the wait
 #pragma unroll
     for (int i = 0; i < SA::NV; ++i) sa.issue_one(i, A);
 #pragma unroll
     for (int i = 0; i < SB::NV; ++i) sb.issue_one(i, B);
+    __syncthreads();
     sa.fetch_step(p.k_a, k_base + 2 * (int64_t)BK);
     sb.fetch_step(p.k_b, k_base + 2 * (int64_t)BK);
 
@@ -392,31 +304,27 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     }
     const T alpha = (T)p.alpha, beta = (T)p.beta;
     int64_t coff[TN];
-    bool cok[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int64_t n = n0 + wn0 + 16 * j + frow;
-        cok[j] = n < p.N;
-        coff[j] = p.col_c[cok[j] ? n : 0];
-    }
+    for (int j = 0; j < TN; ++j) coff[j] = s_coff[BM + wn0 + 16 * j + frow];
+    int64_t roff[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) roff[i][r] = s_coff[wm0 + 16 * i + Tr::acc_row(lane, r)];
     auto store_rows = [&](auto with_beta_t) {
         constexpr bool WITH_BETA = decltype(with_beta_t)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            int64_t roff[4];
-            bool rok[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t m = m0 + wm0 + 16 * i + Tr::acc_row(lane, r);
-                rok[r] = m < p.M;
-                roff[r] = p.row_c[rok[r] ? m : 0];
-            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (rok[r] && cok[j]) {
-                        T *dst = C + roff[r] + coff[j];
+#ifdef CTC_EXP_NOSTORE
+                    if (roff[i][r] != kNoOffset && coff[j] != kNoOffset && acc[i][j][r] == (T)1.2345e30) {
+#else
+                    if (roff[i][r] != kNoOffset && coff[j] != kNoOffset) {
+#endif
+                        T *dst = C + roff[i][r] + coff[j];
                         T v = alpha * acc[i][j][r];
                         if (WITH_BETA) v += beta * *dst;
                         *dst = v;
@@ -425,8 +333,38 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
             }
         }
     };
-    if (beta == (T)0) store_rows(std::false_type());
-    else store_rows(std::true_type());
+    // Same with 16-byte stores (see Traits::cvec): half (f64) or a quarter (f32) of the store
+    // instructions, which is what bounds the epilogue of contractions with a short K.
+    auto store_rows_vec = [&](auto with_beta_t) {
+        constexpr bool WITH_BETA = decltype(with_beta_t)::value;
+        typedef typename Tr::vec_t vec_t;
+        int64_t cvoff[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) cvoff[j] = s_coff[BM + wn0 + 16 * j + (frow & ~(Tr::CV - 1))];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int s = 0; s < Tr::NCV; ++s) {
+                const int64_t rvoff = s_coff[wm0 + 16 * i + Tr::cvec_row(lane, s)];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    vec_t v = Tr::cvec(acc[i][j], lane, s) * alpha;
+                    if (rvoff != kNoOffset && cvoff[j] != kNoOffset) {
+                        vec_t *dst = reinterpret_cast<vec_t *>(C + rvoff + cvoff[j]);
+                        if (WITH_BETA) v += *dst * beta;
+                        *dst = v;
+                    }
+                }
+            }
+        }
+    };
+    if (p.c_vec > 1) {
+        if (beta == (T)0) store_rows_vec(std::false_type());
+        else store_rows_vec(std::true_type());
+    } else {
+        if (beta == (T)0) store_rows(std::false_type());
+        else store_rows(std::true_type());
+    }
 #ifdef CTC_STAMPS
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -30,6 +30,7 @@ struct GemmParams {
     // into `split` K chunks whose raw accumulators go to `ws`
     int dp_tiles = 0, split = 1;
     void *ws = nullptr;
+    int c_vec = 1;  // > 1: C may be stored in 16-byte vectors of that many elements along N
 };
 
 struct GemmSchedule {

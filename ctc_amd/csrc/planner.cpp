@@ -276,6 +276,12 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
         else if (v > 1 && !p.ex_n.empty() && b_unit == p.ex_n[0]) { p.layout_b = kLayoutOuterVec; p.vec_b = v; }
     }
 
+    // C can be stored in 16-byte vectors when its unit-stride mode leads the N modes and
+    // every other C stride keeps the vectors aligned
+    p.vec_c = 1;
+    if (c_unit >= 0 && !p.ex_n.empty() && c_unit == p.ex_n[0] && vector_width(p, p.c_modes, sc, c_unit, vmax) == vmax)
+        p.vec_c = vmax;
+
     build_table(p, p.ex_m, ga, p.M, p.row_a);
     build_table(p, p.ex_k, ga, p.K, p.k_a);
     build_table(p, p.ex_k, gb, p.K, p.k_b);
@@ -388,7 +394,7 @@ std::string describe(const Plan &p)
       << names(p.ex_m) << " n " << names(p.ex_n) << " k " << names(p.ex_k) << " (fastest first)\n";
     o << "gemm M " << p.M << " N " << p.N << " K " << p.K << " batch " << p.batch << "\n";
     o << "layout_a " << lay_name[p.layout_a] << " vec " << p.vec_a << " layout_b "
-      << lay_name[p.layout_b] << " vec " << p.vec_b << "\n";
+      << lay_name[p.layout_b] << " vec " << p.vec_b << " c_vec " << p.vec_c << "\n";
     static const char *kern_name[] = {"mfma_gemm", "skinny_same", "skinny_transpose"};
     o << "kernel " << kern_name[p.kernel];
     if (p.kernel == kKernelSkinnyTranspose) o << " x " << p.sk_X << " y " << p.sk_Y << " o " << p.sk_O;

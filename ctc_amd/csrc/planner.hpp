@@ -55,6 +55,7 @@ struct Plan {
     int64_t M = 1, N = 1, K = 1, batch = 1;
     int layout_a = kLayoutScalar, layout_b = kLayoutScalar;
     int vec_a = 1, vec_b = 1;
+    int vec_c = 1;  // elements per 16-byte store of C along its unit-stride N mode (1: element stores)
     Tile tile;
     std::vector<int64_t> row_a, k_a, k_b, col_b, row_c, col_c, bat_a, bat_b, bat_c;
 

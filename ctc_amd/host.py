@@ -123,7 +123,7 @@ class Plan:
         return "".join(names[i] for i in self.get(query))
 
     def summary(self):
-        bm, bn, bk, threads, la, lb, va, vb, group, kernel = self.get(_lib.Q_TILE)
+        bm, bn, bk, threads, la, lb, va, vb, group, kernel, vc = self.get(_lib.Q_TILE)
         m, n, k, batch = self.get(_lib.Q_GEMM_DIMS)
         return {
             "names": self.names,
@@ -137,7 +137,7 @@ class Plan:
             "exec_n": self._letters(_lib.Q_EXEC_N), "exec_k": self._letters(_lib.Q_EXEC_K),
             "M": m, "N": n, "K": k, "batch_count": batch,
             "tile": (bm, bn, bk), "threads": threads,
-            "layout_a": LAYOUT_NAMES[la], "layout_b": LAYOUT_NAMES[lb], "vec_a": va, "vec_b": vb,
+            "layout_a": LAYOUT_NAMES[la], "layout_b": LAYOUT_NAMES[lb], "vec_a": va, "vec_b": vb, "vec_c": vc,
             "group": group, "kernel": KERNEL_NAMES[kernel],
         }
 

@@ -81,7 +81,7 @@ enum ctc_tc_query {
     CTC_TC_Q_EXEC_N = 13,
     CTC_TC_Q_EXEC_K = 14,
     CTC_TC_Q_GEMM_DIMS = 15,   /* {M, N, K, batch} */
-    CTC_TC_Q_TILE = 16,        /* {BM, BN, BK, threads, layoutA, layoutB, vecA, vecB, group, kernel} */
+    CTC_TC_Q_TILE = 16,        /* {BM, BN, BK, threads, layoutA, layoutB, vecA, vecB, group, kernel, vecC} */
     /* element-offset tables of the execution view: address of GEMM element
      * A(m,k) = A + ROW_A[m] + K_A[k] (+ BAT_A[b]), and so on */
     CTC_TC_Q_ROW_A = 17,

@@ -93,6 +93,60 @@ def test_against_oracle(cuda, oracle, name, spec, ext, dtype):
     _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE[dtype]), dtype)
 
 
+# Short contracted extent, many tiles: the epilogue (16-byte stores of C through the offset
+# tables kept in LDS) carries as much weight as the K loop.  Ragged edges, K tails, every
+# staging layout, batches.
+SHORT_K_CASES = [
+    ("short_k_nn", "ak,kb->ab", dict(a=1100, b=900, k=64), "f64"),
+    ("short_k_nn_k_tail", "ak,kb->ab", dict(a=4100, b=2500, k=70), "f64"),
+    ("short_k_tn", "ka,kb->ab", dict(a=1056, b=2304, k=48), "f64"),
+    ("short_k_nt", "ak,bk->ab", dict(a=1000, b=1200, k=112), "f64"),
+    ("short_k_c_transposed", "ak,kb->ba", dict(a=1300, b=1100, k=96), "f64"),
+    ("short_k_batched", "zak,zkb->zab", dict(z=3, a=700, b=500, k=48), "f64"),
+    ("short_k_six_index", "adij,bcdk->abcijk", dict(a=6, b=5, c=4, i=6, j=4, k=8, d=48), "f64"),
+    ("short_k_scalar_loads", "aeim,bejm->abij", dict(a=9, b=7, i=11, j=6, e=5, m=13), "f64"),
+    ("short_k_odd_n_element_stores", "ak,kb->ab", dict(a=700, b=333, k=40), "f64"),
+    ("short_k_f32_nt", "ak,bk->ab", dict(a=2000, b=1500, k=100), "f32"),
+    ("short_k_f32_tn", "ka,kb->ab", dict(a=1024, b=1152, k=36), "f32"),
+    ("short_k_f32_n_not_multiple_of_4", "ak,kb->ab", dict(a=300, b=1002, k=36), "f32"),
+]
+
+
+@pytest.mark.parametrize("name,spec,ext,dtype", SHORT_K_CASES, ids=[c[0] for c in SHORT_K_CASES])
+def test_short_k_against_oracle(cuda, oracle, name, spec, ext, dtype):
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, dtype, cuda)
+    dC = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+    ctc_amd.Plan(spec, ext, dtype).execute(dA, dB, dC)
+    _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE[dtype]), dtype)
+
+
+def test_vector_stores_alpha_beta(cuda, oracle):
+    spec, ext = "ak,kb->ab", dict(a=2300, b=1700, k=80)
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, "f64", cuda)
+    C0 = oracle.fill(n_out, 99)
+    dC = torch.from_numpy(C0.copy()).to(cuda)
+    plan = ctc_amd.Plan(spec, ext)
+    assert plan.summary()["vec_c"] == 2
+    plan.execute(dA, dB, dC, alpha=0.75, beta=-1.5)
+    want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=0.75, beta=-1.5)
+    _check(dC.cpu().numpy(), want, "f64")
+
+
+@pytest.mark.parametrize("force", ["64", "128"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_c_base_off_the_16_byte_grid(cuda, oracle, monkeypatch, force, dtype):
+    """C one element past an aligned address: the 16-byte store path must not be taken."""
+    monkeypatch.setenv("CTC_TC_FORCE_TILE", force)
+    spec, ext = "ak,kb->ab", dict(a=300, b=264, k=48)
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, dtype, cuda)
+    plan = ctc_amd.Plan(spec, ext, dtype)
+    assert plan.summary()["vec_c"] > 1
+    buf = torch.full((n_out + 1,), float("nan"), dtype=TDT[dtype], device=cuda)
+    plan.execute(dA, dB, buf[1:])
+    _check(buf[1:].cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE[dtype]), dtype)
+    assert torch.isnan(buf[0])
+
+
 def test_skinny_cases_use_the_skinny_kernels():
     kinds = {c[0]: ctc_amd.Plan(c[1], c[2], c[3]).summary()["kernel"] for c in CASES if c[0].startswith("skinny")}
     assert kinds["skinny_transpose_ragged"] == "skinny_transpose"
