@@ -46,6 +46,19 @@ def cpu_baseline(extent, threads):
     return 2.0 * n ** 6 / dt * 1e-12, dt, float(np.abs(C).max())
 
 
+def measured_traffic(extent, kernel_summary):
+    """HBM-side bytes per launch from the committed counter passes (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE, one pass each, tools/pmc_traffic.sh); None when they do not cover this run."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_traffic.json")
+    if extent != 96 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    if "128, 128" not in t.get("kernel", "") or tuple(kernel_summary["tile"][:2]) != (128, 128):
+        return None
+    return t["per_launch_bytes"]["total_corrected"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +153,9 @@ def main():
                 "peak": PEAK_FP64_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
-                "traffic": None,
+                "traffic": measured_traffic(n, s) if world == 1 else None,
+                "traffic_unit": "bytes per launch at the L2's memory side (separate counter passes, profiles/r01_bench_traffic.json)",
+                "algorithmic_bytes_per_launch": 3 * 8 * n ** 4,
                 "kernel": "gemm_kernel<double>",
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_flops_per_launch": flops_rank,
