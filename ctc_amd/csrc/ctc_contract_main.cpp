@@ -10,6 +10,8 @@
 //                [--describe]                  print the plan and exit (needs no GPU)
 //                [--shard MODE:RANK/NRANKS]    compute one slab only
 //                [--time ITERS]                print device ms per contraction
+//   ctc_contract --permute abcd=dcba --extents a=..,b=.. --dtype f32 --a IN.bin --out OUT.bin
+//                                              mode permutation of one tensor (input modes = output modes)
 //
 // Because the engine runs the command through a shell, write the spec with '='
 // instead of '->' inside plugin templates.
@@ -76,13 +78,15 @@ int main(int argc, char **argv)
         if (a == "--help" || a == "-h") {
             printf("usage: ctc_contract --spec S --extents a=..,b=.. [--dtype f64|f32] --a FILE --b FILE --out FILE\n"
                    "       [--alpha X] [--beta Y] [--gen-a SEED] [--gen-b SEED] [--describe]\n"
-                   "       [--shard MODE:RANK/NRANKS] [--time ITERS] [--device N]\n");
+                   "       [--shard MODE:RANK/NRANKS] [--time ITERS] [--device N]\n"
+                   "       ctc_contract --permute IN=OUT --extents ... [--dtype T] --a FILE --out FILE\n");
             return 0;
         }
         if (a.size() < 3 || a.substr(0, 2) != "--" || i + 1 >= argc) die("bad argument '" + a + "'");
         opt[a.substr(2)] = argv[++i];
     }
-    if (!opt.count("spec") || !opt.count("extents")) die("--spec and --extents are required");
+    if (!(opt.count("spec") || opt.count("permute")) || !opt.count("extents"))
+        die("--spec (or --permute) and --extents are required");
 
     std::string names;
     std::vector<int64_t> extents;
@@ -107,6 +111,47 @@ int main(int argc, char **argv)
         else die("unknown --dtype " + opt["dtype"]);
     }
     const size_t es = dtype == CTC_TC_F64 ? 8 : dtype == CTC_TC_F32 ? 4 : 2;
+
+    if (opt.count("permute")) {
+        // IN=OUT (or IN->OUT): the same letters on both sides
+        std::string ps = opt["permute"];
+        size_t sep = ps.find("->"), seplen = 2;
+        if (sep == std::string::npos) { sep = ps.find('='); seplen = 1; }
+        if (sep == std::string::npos) die("bad --permute, want INMODES=OUTMODES");
+        const std::string in_modes = ps.substr(0, sep), out_modes = ps.substr(sep + seplen);
+        if (in_modes.empty() || in_modes.size() != out_modes.size()) die("--permute: both sides need the same modes");
+        std::vector<int64_t> ext_in;
+        std::vector<int> perm;
+        size_t n = 1;
+        for (char ch : in_modes) {
+            size_t at = names.find(ch);
+            if (at == std::string::npos) die(std::string("no extent for mode ") + ch);
+            if (in_modes.find(ch) != in_modes.rfind(ch)) die(std::string("mode repeated in --permute: ") + ch);
+            ext_in.push_back(extents[at]);
+            n *= (size_t)extents[at];
+        }
+        for (char ch : out_modes) {
+            size_t at = in_modes.find(ch);
+            if (at == std::string::npos || out_modes.find(ch) != out_modes.rfind(ch))
+                die("--permute: the output modes must be a permutation of the input modes");
+            perm.push_back((int)at);
+        }
+        if (!opt.count("a") || !opt.count("out")) die("--permute needs --a IN and --out OUT");
+        if (ctc_tc_device_count() < 1) die("no HIP device visible (this tool has no CPU path)");
+        if (opt.count("device")) hip_check(hipSetDevice(atoi(opt["device"].c_str())), "hipSetDevice");
+        std::vector<char> h = read_file(opt["a"], n * es);
+        void *d_in = nullptr, *d_out = nullptr;
+        hip_check(hipMalloc(&d_in, n * es), "hipMalloc in");
+        hip_check(hipMalloc(&d_out, n * es), "hipMalloc out");
+        hip_check(hipMemcpy(d_in, h.data(), n * es, hipMemcpyHostToDevice), "copy in");
+        check(ctc_tc_permute(d_in, d_out, (int)perm.size(), ext_in.data(), perm.data(), (int)es, nullptr), "permute");
+        hip_check(hipDeviceSynchronize(), "synchronize");
+        hip_check(hipMemcpy(h.data(), d_out, n * es, hipMemcpyDeviceToHost), "copy out");
+        write_file(opt["out"], h.data(), n * es);
+        (void)hipFree(d_in);
+        (void)hipFree(d_out);
+        return 0;
+    }
 
     ctc_tc_plan *plan = nullptr;
     check(ctc_tc_plan_create(opt["spec"].c_str(), (int)names.size(), names.data(), extents.data(), nullptr,

@@ -173,6 +173,81 @@ def plugin_commands(plugin_id, params, engine_root=ENGINE_ROOT, env=None):
     return plugin.exec_commands(params, {"ENGINE_DIR": root}, env)
 
 
+def _catalog_file(engine_root, tag, item_id):
+    root = ET.parse(os.path.join(engine_root, "catalog.xml")).getroot()
+    for suite in root:
+        for item in suite:
+            if item.tag == tag and item.attrib.get("id") == item_id:
+                return os.path.join(engine_root, item.attrib["file"])
+    raise EngineError("%s not in catalog: %s" % (tag, item_id))
+
+
+class Workflow:
+    """A workflow descriptor as the engine reads it (engine/src/ctc_workflow.cpp:38-144)."""
+
+    def __init__(self, path):
+        root = ET.parse(path).getroot()
+        self.id = root.attrib["id"]
+        self.inputs = {p.attrib["name"]: dict(p.attrib) for p in root.find("inputs")}
+        self.steps = []
+        for st in root.find("steps"):
+            if st.attrib["type"] != "plugin":
+                raise EngineError("only plugin steps are mirrored here")
+            self.steps.append({
+                "id": st.attrib["id"], "plugin_id": st.attrib["plugin_id"],
+                "inputs": [(p.attrib["name"], p.attrib["value"]) for p in st.find("inputs")],
+                "outputs": [p.attrib["name"] for p in st.find("outputs")]})
+        self.outputs = {}
+        for p in root.find("outputs"):
+            if "type" not in p.attrib:
+                raise EngineError("Missing \"type\" in the workflow definition")
+            self.outputs[p.attrib["name"]] = p.attrib["value"]
+
+
+def workflow_commands(workflow_id, params, workdir, engine_root=ENGINE_ROOT, org_dir="/", env=None):
+    """What Engine::executeWorkflow does with these call parameters
+    (engine/src/ctc_engine.cpp:186-311): returns (commands, moves).  `workdir` stands for the
+    mkdtemp directory the engine changes into; `name.param` call parameters go to step `name`;
+    each step output gets <workdir>/<step>-<plugin>-<param>.tmp[.format], and later steps see
+    it as $<step>.<param> WITHOUT the directory (they run inside it)."""
+    root = os.path.abspath(engine_root)
+    if not root.endswith("/"):
+        root += "/"
+    wf = Workflow(_catalog_file(root, "workflow", workflow_id))
+    sys_params = {"ENGINE_DIR": root}
+    exec_params, step_params = {}, {st["id"]: {} for st in wf.steps}
+    for name, value in params.items():
+        if "." in name:
+            sid, rest = name.split(".", 1)
+            if sid not in step_params:
+                raise EngineError("Cannot find matched step for parameter " + name)
+            step_params[sid][rest] = value
+        else:
+            exec_params[name] = value
+    commands = []
+    for st in wf.steps:
+        sp = step_params[st["id"]]
+        # std::map iteration order: by parameter name
+        for name, value in sorted(st["inputs"]):
+            if name not in sp:
+                sp[name] = resolve_word(value, exec_params, sys_params, env)
+        plugin = Plugin(catalog_plugin_file(root, st["plugin_id"]))
+        for name in sorted(st["outputs"]):
+            fmt = plugin.outputs.get(name, plugin.inputs.get(name, {"format": ""}))["format"]
+            tmp = "%s-%s-%s.tmp" % (st["id"], st["plugin_id"], name) + ("." + fmt if fmt else "")
+            sp[name] = workdir + "/" + tmp
+            exec_params["%s.%s" % (st["id"], name)] = tmp
+        commands += plugin.exec_commands(sp, sys_params, env)
+    moves = []
+    for name in sorted(wf.outputs):
+        source = resolve_word(wf.outputs[name], exec_params, sys_params, env)
+        dest = exec_params.get(name, "")
+        if not dest.startswith("/"):
+            dest = org_dir + "/" + dest
+        moves.append((source, dest))
+    return commands, moves
+
+
 def cli_command(engine_root, kind, words, test=False):
     """The line the engine's interactive CLI hands to os.system for executePlugin/testPlugin/
     executeWorkflow/testWorkflow (engine/cli/cli.py:98-133)."""

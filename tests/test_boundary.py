@@ -109,3 +109,59 @@ def test_config1_through_the_unchanged_engine(tmp_path, oracle, ext):
     want = oracle.contract("adc,db->abc", ext, A, B)
     assert got.shape == want.shape
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def _engine_workflow_dry_run(workflow, params, cwd):
+    argv = [ENGINE, eb.ENGINE_ROOT, "--test", "workflow", workflow]
+    for k, v in params.items():
+        argv += ["--" + k, v]
+    log = subprocess.run(argv, capture_output=True, text=True, cwd=str(cwd)).stdout
+    workdir = re.findall(r"Changing working directory to (\S+)", log)[0]
+    commands = re.findall(r"Executing: (.*)", log)
+    moves = re.findall(r"Moving file from (\S+) to (\S+)", log)
+    return workdir, commands, moves
+
+
+@pytest.mark.skipif(not os.path.exists(ENGINE), reason="reference engine not built (oracle/build_ref.sh)")
+def test_reference_engine_workflow_dry_run_equals_mirror(tmp_path):
+    """Two-step workflow (permute, then contract): temp-file names, step parameters and the final
+    move as the unchanged engine logs them (engine/src/ctc_engine.cpp:186-311)."""
+    params = {"input_a": "/d/A.bin", "input_b": "/d/B.bin", "modes": "adc=acd", "spec": "acd,db=abc",
+              "extents": "a=8,b=6,c=5,d=7", "output_c": "/d/C.bin", "perm.dtype": "f32", "mult.dtype": "f32",
+              "mult.alpha": "0.5"}
+    workdir, commands, moves = _engine_workflow_dry_run("permute_contract", params, tmp_path)
+    want_cmds, want_moves = eb.workflow_commands("permute_contract", params, workdir)
+    assert commands == want_cmds
+    assert [tuple(m) for m in moves] == want_moves
+    assert "--a perm-permute-output_t.tmp.tensor" in commands[1]  # later steps name the file without the directory
+    # a relative final output lands in the caller's directory
+    params["output_c"] = "C.bin"
+    workdir, commands, moves = _engine_workflow_dry_run("permute_contract", params, tmp_path)
+    assert moves == [("mult-contract-output_c.tmp.tensor", str(tmp_path) + "/C.bin")]
+
+
+def test_workflow_mirror_rejects_unknown_step():
+    with pytest.raises(eb.EngineError):
+        eb.workflow_commands("permute_contract", {"nostep.dtype": "f32"}, "/W")
+
+
+@pytest.mark.gpu
+def test_permute_then_contract_workflow_through_the_unchanged_engine(tmp_path, oracle):
+    """A stored as [a,d,c] is permuted to [a,c,d] by step 1 and contracted by step 2; the engine
+    moves the result to the requested file."""
+    if not os.path.exists(ENGINE):
+        pytest.fail("oracle/_ref/execute_engine missing: run oracle/build_ref.sh where /root/reference exists")
+    ext = dict(a=32, b=48, c=16, d=24)
+    A = oracle.fill(ext["a"] * ext["d"] * ext["c"], 0xC7C0A)
+    B = oracle.fill(ext["d"] * ext["b"], 0xC7C0B)
+    A.tofile(tmp_path / "A.bin")
+    B.tofile(tmp_path / "B.bin")
+    extents = ",".join("%s=%d" % kv for kv in ext.items())
+    run = subprocess.run([ENGINE, eb.ENGINE_ROOT, "workflow", "permute_contract", "--modes", "adc=acd", "--spec", "acd,db=abc",
+                          "--extents", extents, "--input_a", str(tmp_path / "A.bin"), "--input_b", str(tmp_path / "B.bin"),
+                          "--output_c", str(tmp_path / "C.bin")], capture_output=True, text=True, cwd=str(tmp_path))
+    assert os.path.exists(tmp_path / "C.bin"), run.stdout + run.stderr
+    got = np.fromfile(tmp_path / "C.bin", dtype=np.float64)
+    want = oracle.contract("adc,db->abc", ext, A, B)   # same result as contracting the unpermuted A
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
