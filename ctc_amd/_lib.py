@@ -19,7 +19,7 @@ SYMBOLS = (
     "ctc_tc_grouped_contract",
 )
 # every symbol include/ctc_fastr.h declares
-FASTR_SYMBOLS = ("ctc_fastr_best_offsets",)
+FASTR_SYMBOLS = ("ctc_fastr_best_offsets", "ctc_fastr_sw_align", "ctc_fastr_sw_workspace_bytes")
 
 F64, F32, BF16 = 0, 1, 2
 

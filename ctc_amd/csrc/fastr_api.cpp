@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -114,5 +115,51 @@ extern "C" int ctc_fastr_best_offsets(const uint8_t *d_ref, const uint8_t *d_rea
     p.read_stride = read_stride;
     e = ctc::launch_fastr(p, (int)work.size(), staged, s);
     if (e != hipSuccess) return set_last_error(CTC_TC_EDEVICE, std::string("scoring kernel launch: ") + hipGetErrorString(e));
+    return CTC_TC_OK;
+}
+
+extern "C" size_t ctc_fastr_sw_workspace_bytes(int n_pairs, int max_ref_len, int max_read_len)
+{
+    if (n_pairs <= 0 || max_ref_len <= 0 || max_read_len <= 0) return 0;
+    return (size_t)n_pairs * ctc::sw_bt_elems_per_pair(max_ref_len, max_read_len) * sizeof(short);
+}
+
+extern "C" int ctc_fastr_sw_align(const uint8_t *d_ref, const int64_t *d_ref_off, const int32_t *d_ref_len,
+                                  const uint8_t *d_reads, int read_stride, const int32_t *d_read_len, int n_pairs,
+                                  double w_match, double w_mismatch, double w_open, double w_extend, int max_ref_len,
+                                  int max_read_len, int32_t *d_offset, int32_t *d_n_ops, uint8_t *d_op_type,
+                                  int32_t *d_op_len, int max_ops, void *d_workspace, size_t workspace_bytes,
+                                  void *stream)
+{
+    using ctc_internal::set_last_error;
+    if (n_pairs < 0 || read_stride <= 0 || max_ops <= 0) return set_last_error(CTC_TC_EINVAL, "bad n_pairs, read_stride or max_ops");
+    if (n_pairs == 0) return CTC_TC_OK;
+    if (!d_ref || !d_ref_off || !d_ref_len || !d_reads || !d_read_len || !d_offset || !d_n_ops || !d_op_type || !d_op_len ||
+        !d_workspace)
+        return set_last_error(CTC_TC_EINVAL, "null argument");
+    if (max_ref_len <= 0 || max_ref_len > 32767)
+        return set_last_error(CTC_TC_EUNSUPPORTED, "max_ref_len must be in 1..32767 (back-track entries are int16)");
+    if (max_read_len <= 0 || max_read_len > read_stride)
+        return set_last_error(CTC_TC_EINVAL, "max_read_len must be in 1..read_stride");
+    if (ctc::sw_lds_bytes(max_read_len, max_ops) > 64 * 1024)
+        return set_last_error(CTC_TC_EUNSUPPORTED, "max_read_len and max_ops need more than 64 KB of LDS per workgroup");
+    const size_t per_pair = ctc::sw_bt_elems_per_pair(max_ref_len, max_read_len) * sizeof(short);
+    const size_t fit = workspace_bytes / per_pair;
+    if (fit == 0) return set_last_error(CTC_TC_EINVAL, "workspace smaller than one pair's back-track store");
+    ctc::SwParams p;
+    p.ref = d_ref; p.reads = d_reads; p.ref_off = d_ref_off; p.ref_len = d_ref_len; p.read_len = d_read_len;
+    p.read_stride = read_stride;
+    p.w_match = w_match; p.w_mismatch = w_mismatch; p.w_open = w_open; p.w_extend = w_extend;
+    p.max_ref_len = max_ref_len; p.max_read_len = max_read_len; p.max_ops = max_ops;
+    p.bt = static_cast<short *>(d_workspace);
+    p.bt_per_pair = per_pair / sizeof(short);
+    p.offset = d_offset; p.n_ops = d_n_ops; p.op_len = d_op_len; p.op_type = d_op_type;
+    // as many launches as the workspace asks for; they run one after the other on the stream
+    for (long long first = 0; first < n_pairs; first += (long long)fit) {
+        p.first_pair = first;
+        p.n_pairs = (int)std::min<long long>((long long)fit, n_pairs - first);
+        const hipError_t e = ctc::launch_sw(p, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return set_last_error(CTC_TC_EDEVICE, std::string("alignment kernel launch: ") + hipGetErrorString(e));
+    }
     return CTC_TC_OK;
 }

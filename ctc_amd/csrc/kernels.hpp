@@ -94,6 +94,25 @@ int fastr_max_read_lds();
 int fastr_reads_per_block();
 hipError_t launch_fastr(const FastrParams &p, int n_blocks, bool staged, hipStream_t stream);
 
+// Batched pairwise alignment (sw_kernels.hip): pair q of a launch is global pair first_pair + q.
+struct SwParams {
+    const unsigned char *ref = nullptr, *reads = nullptr;
+    const int64_t *ref_off = nullptr;
+    const int32_t *ref_len = nullptr, *read_len = nullptr;
+    int read_stride = 0;
+    long long first_pair = 0;
+    int n_pairs = 0;
+    double w_match = 0, w_mismatch = 0, w_open = 0, w_extend = 0;
+    int max_ref_len = 0, max_read_len = 0, max_ops = 0;
+    short *bt = nullptr;        // back-track store, bt_per_pair int16 per pair of the launch
+    size_t bt_per_pair = 0;
+    int32_t *offset = nullptr, *n_ops = nullptr, *op_len = nullptr;
+    unsigned char *op_type = nullptr;
+};
+size_t sw_lds_bytes(int max_read_len, int max_ops);
+size_t sw_bt_elems_per_pair(int max_ref_len, int max_read_len);
+hipError_t launch_sw(const SwParams &p, hipStream_t stream);
+
 // Generic tiled permutation through element-offset tables (see permute_kernels.hip).
 struct PermuteParams {
     const void *in = nullptr;

@@ -60,3 +60,71 @@ class DeviceBatch:
 def best_offsets(batch, device="cuda:0"):
     """(best_score, best_index) numpy arrays for a host batch: upload, score on the GPU, download."""
     return DeviceBatch(batch, device).run().results()
+
+
+# ---- pairwise alignment (apps/fastr/SWPairwiseAlignment.cpp) ----------------------------------
+DEFAULT_SW_WEIGHTS = (30.0, -10.0, -10.0, -2.0)  # apps/fastr/IndelRealigner.cpp:165-168
+_sw_bound = False
+
+
+def _sw_fns():
+    global _sw_bound
+    L = _lib.load()
+    if not _sw_bound:
+        vp, dbl, ci = ctypes.c_void_p, ctypes.c_double, ctypes.c_int
+        L.ctc_fastr_sw_workspace_bytes.restype = ctypes.c_size_t
+        L.ctc_fastr_sw_workspace_bytes.argtypes = [ci, ci, ci]
+        L.ctc_fastr_sw_align.restype = ci
+        L.ctc_fastr_sw_align.argtypes = [vp, vp, vp, vp, ci, vp, ci, dbl, dbl, dbl, dbl, ci, ci, vp, vp, vp, vp, ci,
+                                         vp, ctypes.c_size_t, vp]
+        _sw_bound = True
+    return L.ctc_fastr_sw_workspace_bytes, L.ctc_fastr_sw_align
+
+
+class DeviceAlignmentBatch:
+    """Reads and their reference windows resident in HBM.  `batch`: ref (uint8, windows back to
+    back), ref_off (int64) and ref_len (int32) per pair, reads (uint8 [pairs][read_stride]),
+    read_len (int32), read_stride."""
+
+    def __init__(self, batch, device, max_ops=64, workspace_pairs=None):
+        import torch
+        self.device = device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        self.ref = up(batch["ref"])
+        self.ref_off = up(batch["ref_off"].astype(np.int64))
+        self.ref_len = up(batch["ref_len"].astype(np.int32))
+        self.reads = up(batch["reads"])
+        self.read_len = up(batch["read_len"].astype(np.int32))
+        self.read_stride = int(batch["read_stride"])
+        self.n_pairs = int(batch["read_len"].size)
+        self.max_ref_len = int(batch["ref_len"].max()) if self.n_pairs else 1
+        self.max_read_len = int(batch["read_len"].max()) if self.n_pairs else 1
+        self.max_ops = max_ops
+        n = max(self.n_pairs, 1)
+        self.offset = torch.empty(n, dtype=torch.int32, device=device)
+        self.n_ops = torch.empty(n, dtype=torch.int32, device=device)
+        self.op_type = torch.empty(n * max_ops, dtype=torch.uint8, device=device)
+        self.op_len = torch.empty(n * max_ops, dtype=torch.int32, device=device)
+        ws_fn, _ = _sw_fns()
+        pairs = self.n_pairs if workspace_pairs is None else min(workspace_pairs, self.n_pairs)
+        self.workspace_bytes = int(ws_fn(max(pairs, 1), self.max_ref_len, self.max_read_len))
+        self.workspace = torch.empty(max(self.workspace_bytes, 1), dtype=torch.uint8, device=device)
+
+    def run(self, weights=DEFAULT_SW_WEIGHTS, stream=None):
+        _, fn = _sw_fns()
+        check(fn(_ptr(self.ref), _ptr(self.ref_off), _ptr(self.ref_len), _ptr(self.reads), self.read_stride,
+                 _ptr(self.read_len), self.n_pairs, *[float(w) for w in weights], self.max_ref_len, self.max_read_len,
+                 _ptr(self.offset), _ptr(self.n_ops), _ptr(self.op_type), _ptr(self.op_len), self.max_ops,
+                 _ptr(self.workspace), self.workspace_bytes, _stream(stream)))
+        return self
+
+    def results(self):
+        n = self.n_pairs
+        return (self.offset[:n].cpu().numpy(), self.n_ops[:n].cpu().numpy(),
+                self.op_type[:n * self.max_ops].cpu().numpy().reshape(n, self.max_ops),
+                self.op_len[:n * self.max_ops].cpu().numpy().reshape(n, self.max_ops))
+
+
+def sw_align(batch, device="cuda:0", weights=DEFAULT_SW_WEIGHTS, max_ops=64):
+    """(offset, n_ops, op_type, op_len) numpy arrays for a host batch of (window, read) pairs."""
+    return DeviceAlignmentBatch(batch, device, max_ops).run(weights).results()

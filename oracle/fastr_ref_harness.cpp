@@ -6,6 +6,7 @@
 //   mismatchQualitySumIgnoreCigar   apps/fastr/IndelRealigner.cpp:264-295
 //   findBestOffset                  apps/fastr/IndelRealigner.cpp:502-542
 //   ch_lookup initialisation        apps/fastr/IndelRealigner.cpp:1142-1149
+//   SWPairwiseAlignment             apps/fastr/SWPairwiseAlignment.cpp:64-71,94-399 (its own translation unit)
 // and exposes them through a C entry point.  Built by oracle/build_ref.sh into
 // oracle/_ref/libfastr_ref.so.
 #define main fastr_reference_main
@@ -36,4 +37,21 @@ extern "C" int fastr_ref_find_best_offset(const char *ref, int ref_len, const ch
     *best_index = p.first;
     *best_score = p.second;
     return 0;
+}
+
+// The reference's pairwise aligner as createAndAddAlternateConsensus calls it
+// (apps/fastr/IndelRealigner.cpp:366-371): sequence 1 = reference window, sequence 2 = read.
+extern "C" int fastr_ref_sw_align(const char *ref, int ref_len, const char *read, int read_len, double match,
+                                  double mismatch, double open, double extend, int *alignment_offset,
+                                  char *op_type, int *op_len, int max_ops)
+{
+    SWPairwiseAlignment sw((const byte *)ref, (unsigned)ref_len, (const byte *)read, (unsigned)read_len, match,
+                           mismatch, open, extend);
+    *alignment_offset = sw.getAlignmentStart2wrt1();
+    Cigar c = sw.getCigar();
+    for (size_t k = 0; k < c.size() && (int)k < max_ops; ++k) {
+        op_type[k] = c[k].Type;
+        op_len[k] = (int)c[k].Length;
+    }
+    return (int)c.size();
 }
