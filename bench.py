@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--extent", type=int, default=96, help="extent of every mode (64..96 in BASELINE)")
     ap.add_argument("--cpu-extent", type=int, default=96, help="extent of the CPU-oracle sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--prewarm", type=float, default=0.1, help="seconds of untimed load before the warm-up steps")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +106,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The chip needs some tens of milliseconds of load before it holds its clocks (the first
+    # 30 ms of launches run about 7 % slower): load it for a fixed time, untimed, before the
+    # W warm-up steps, so that short configurations are measured in the same state as long ones.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm:
+        plan.execute(A, B, C)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         plan.execute(A, B, C)
     barrier()

@@ -1,7 +1,7 @@
 """Secondary measurements (BASELINE configs 3 and 5, plus kernel variants).  The headline
 (config 2) lives in bench.py; this script prints one JSON line per measurement.
 
-  python benchmarks/run_configs.py [permute] [adversarial] [f32] [small] [ttgt]
+  python benchmarks/run_configs.py [permute] [adversarial] [f32] [six] [small] [fastr] [sw] [ttgt]
 """
 import json
 import os
@@ -160,7 +160,38 @@ def main():
                           "full_scan_Gcompare/s": round(compares / ms * 1e-6, 1),
                           "bytes_moved": int(in_bytes), "GB/s": round(in_bytes / ms * 1e-6, 2),
                           "cpu_oracle_s": round(cpu_s, 3), "cpu_threads": min(16, os.cpu_count() or 1)}))
+    if "sw" in what:
+        import numpy as np
+        from ctc_amd import fastr
+        from oracle import sw as osw
+        # 64 windows x U{20..100} reads of 60..160 bases against windows of 200..1200 bases
+        b = osw.make_pairs(seed=0x5117, n_windows=64, reads_per_window=(20, 100))
+        d = fastr.DeviceAlignmentBatch(b, DEV)
+        ms = time_ms(lambda: d.run(), warmup=2, iters=10)
+        threads = min(16, os.cpu_count() or 1)
+        t0 = time.perf_counter()
+        w_off, w_n, w_ty, w_ln = osw.align_batch(b, threads=threads)
+        cpu_s = time.perf_counter() - t0
+        off, n_ops, ty, ln = d.results()
+        exact = bool(np.array_equal(off, w_off) and np.array_equal(n_ops, w_n) and
+                     osw.cigar_strings(n_ops, ty, ln) == osw.cigar_strings(w_n, w_ty, w_ln))
+        cells = int((b["ref_len"].astype(np.int64) * b["read_len"].astype(np.int64)).sum())
+        print(json.dumps({"workload": "pairwise alignment batch: %d (window, read) pairs" % d.n_pairs,
+                          "ms": round(ms, 4), "pairs/s": round(d.n_pairs / ms * 1e3), "cells": cells,
+                          "Gcell/s": round(cells / ms * 1e-6, 2), "bit_exact_vs_oracle": exact,
+                          "backtrack_store_MB": round(d.workspace_bytes / 1e6, 1),
+                          "cpu_oracle_s": round(cpu_s, 3), "cpu_Gcell/s": round(cells / cpu_s * 1e-9, 3),
+                          "cpu_threads": threads}))
     if "ttgt" in what:
+        # odd extents: no 16-byte vectors are legal, the fused kernel loads element by element
+        for n in (63, 75):
+            e = dict(a=n, b=n, i=n, j=n, e=n, m=n)
+            contraction_case("aeim,ebmj->abij", e, "f64", "ccsd fp64 extent %d (odd: element loads)" % n, ttgt=True)
+            contraction_case("aeim,ebmj->abij", e, "f64", "ccsd fp64 extent %d (odd: element loads)" % n)
+        # operands whose unit-stride mode is on the "wrong" side: A's fastest mode is free, B's is contracted
+        e = dict(a=64, b=64, i=64, j=64, e=64, m=64)
+        contraction_case("eaim,jbem->abij", e, "f64", "ccsd fp64 extent 64, A outer-major / B K-major", ttgt=True)
+        contraction_case("eaim,jbem->abij", e, "f64", "ccsd fp64 extent 64, A outer-major / B K-major")
         n = 64
         contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "f64", "ccsd fp64 extent 64", ttgt=True)
         contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "f64", "ccsd fp64 extent 64")
