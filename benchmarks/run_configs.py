@@ -1,7 +1,7 @@
 """Secondary measurements (BASELINE configs 3 and 5, plus kernel variants).  The headline
 (config 2) lives in bench.py; this script prints one JSON line per measurement.
 
-  python benchmarks/run_configs.py [permute] [adversarial] [f32] [six] [small] [fastr] [sw] [ttgt]
+  python benchmarks/run_configs.py [permute] [adversarial] [f32] [bf16] [six] [small] [fastr] [sw] [ttgt]
 """
 import json
 import os
@@ -48,7 +48,7 @@ def permute_case(shape, perm, dtype=torch.float32, name=None):
 
 
 def contraction_case(spec, ext, dtype, name, ttgt=False):
-    tdt = {"f64": torch.float64, "f32": torch.float32}[dtype]
+    tdt = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}[dtype]
     ins, outm = spec.split("->")
     la, lb = ins.split(",")
     n = lambda s: int(torch.tensor([ext[c] for c in s]).prod()) if s else 1  # noqa: E731
@@ -90,6 +90,12 @@ def main():
     if "f32" in what:
         for n in (64, 96):
             contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "f32", "ccsd fp32 extent %d" % n)
+    if "bf16" in what:
+        for n in (64, 96):
+            contraction_case("aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n), "bf16", "ccsd bf16 extent %d" % n)
+        contraction_case("ak,bk->ab", dict(a=8192, b=8192, k=8192), "bf16", "plain GEMM bf16 8192^3, both operands K-major")
+        contraction_case("ka,kb->ab", dict(a=8192, b=8192, k=8192), "bf16", "plain GEMM bf16 8192^3, both operands outer-major")
+        contraction_case("aeim,ebmj->abij", dict(a=63, b=63, i=63, j=63, e=63, m=63), "bf16", "ccsd bf16 extent 63 (element loads)")
     if "six" in what:
         # config 4: abcijk = adij, bcdk, free extents 40, d = 64; one GPU's slab of the free index a (5 of 40)
         e = dict(a=5, b=40, c=40, i=40, j=40, k=40, d=64)

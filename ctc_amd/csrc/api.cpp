@@ -221,7 +221,6 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
                 hipStream_t stream)
 {
     const ctc::Plan &p = pl->plan;
-    if (p.dtype == ctc::kBF16) return fail(CTC_TC_EUNSUPPORTED, "bf16 contractions are not implemented yet");
     int device = 0;
     int rc = current_device(device);
     if (rc) return rc;
@@ -271,6 +270,12 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     int la = p.layout_a, lb = p.layout_b;
     if (la != ctc::kLayoutScalar && (reinterpret_cast<uintptr_t>(g.A) & 15)) la = ctc::kLayoutScalar;
     if (lb != ctc::kLayoutScalar && (reinterpret_cast<uintptr_t>(g.B) & 15)) lb = ctc::kLayoutScalar;
+
+    if (p.dtype == ctc::kBF16) {
+        hipError_t be = ctc::launch_gemm_bf16(la, lb, g, stream);
+        if (be != hipSuccess) return fail_hip(be, "bf16 contraction kernel launch");
+        return CTC_TC_OK;
+    }
 
     ctc::GemmSchedule sch;
     hipError_t e = ctc::schedule_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, &sch);

@@ -1,0 +1,366 @@
+// bf16 MFMA GEMM for tensor contractions on gfx950 (bf16 operands, f32 accumulation,
+// bf16 result rounded to nearest even once), with the mode permutation fused into the
+// operand loads through the same element-offset tables as the f64/f32 kernel.
+//
+// v_mfma_f32_16x16x32_bf16 wants, in lane l, eight consecutive k of one row (A) or one
+// column (B): A[row l&15][k = 8(l>>4) + j], B[k = 8(l>>4) + j][col l&15], j = 0..7.  A
+// workgroup (2 x 2 waves) owns a 128 x 128 tile of C and walks K in tiles of 64; each
+// operand tile lives in LDS in one of two images, chosen by which GEMM dimension is
+// unit-stride in memory:
+//   K-major image  [row][64 k], 128-byte rows.  The 16-byte chunk c (8 k) of row r sits at
+//                  128 r + 16 (c ^ ((r >> 1) & 7)).  Filled with 16-byte vectors along K
+//                  (or element by element when no vectors are legal); a fragment is one
+//                  ds_read_b128.  The XOR makes the sixteen lanes ds_read_b128 services
+//                  together ({0-3, 12-15, 20-27}, ...: eight rows at chunk c and eight at
+//                  chunk c ^ 1) fall on sixteen different 16-byte slots of the 256-byte
+//                  bank row.
+//   outer image    [k][128 rows], 256-byte rows, chunk c (8 rows) of line k at
+//                  256 k + 16 (c ^ (((k & 3) << 2) | ((k >> 2) & 3))).  Filled with 16-byte
+//                  vectors along the rows; a fragment is two ds_read_b64_tr_b16 (the
+//                  hardware transposes a block of 4 k x 16 rows per 16 lanes), conflict-free
+//                  because the two blocks a 32-lane half reads are 8 lines apart.
+// Staging is global -> registers -> LDS with two LDS buffers: the loads of tile t+1 are in
+// flight while tile t feeds the MFMAs, one barrier per tile; two workgroups share a CU.
+#include "gemm_device.hpp"
+#include "kernels.hpp"
+
+namespace ctc {
+
+namespace {
+
+using gemm_detail::kLayOuterVec;
+using gemm_detail::kLayScalar;
+
+typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+typedef short s4_t __attribute__((ext_vector_type(4)));
+typedef short s8_t __attribute__((ext_vector_type(8)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
+constexpr int kImageBytes = 128 * BK * 2;  // either image of a 128-row operand tile: 16 KiB
+
+__device__ __forceinline__ int kmaj_off(int row, int chunk) { return 128 * row + 16 * (chunk ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ int outer_off(int k, int chunk)
+{
+    return 256 * k + 16 * (chunk ^ (((k & 3) << 2) | ((k >> 2) & 3)));
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x0040u);  // NaN stays NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// Stages one 128 x 64 operand tile.  tab_rows / tab_k are the operand's element-offset
+// tables (rows: M or N index, k: K index; the device k tables carry kKTablePad extra
+// entries, so k0 + 63 is always a valid index).  Rows past the operand's extent are
+// clamped (their products land in C elements that are never stored); k past K reads
+// as zero.
+template <int LAY> struct StagerBf16;
+
+template <> struct StagerBf16<0 /* unit stride along K */> {
+    static constexpr bool OUTER = false;
+    int64_t fix_off[4];
+    u4_t regs[4];
+    int chunk, row0;
+    __device__ __forceinline__ void init(const int64_t *__restrict__ tab_rows, int64_t r0, int64_t R, int t)
+    {
+        chunk = t & 7;
+        row0 = t >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t r = r0 + row0 + 32 * i;
+            fix_off[i] = tab_rows[r < R ? r : R - 1];
+        }
+    }
+    __device__ __forceinline__ void issue(const unsigned short *__restrict__ base, const int64_t *__restrict__ tab_k,
+                                          int64_t k0, int64_t)
+    {
+        const int64_t ko = tab_k[k0 + 8 * chunk];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) regs[i] = *reinterpret_cast<const u4_t *>(base + fix_off[i] + ko);
+    }
+    __device__ __forceinline__ void commit(unsigned char *lds, int64_t k0, int64_t K)
+    {
+        const bool live = k0 + 8 * chunk < K;  // K is a multiple of 8 whenever this layout is chosen
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u4_t v = regs[i];
+            if (!live) v = u4_t{0, 0, 0, 0};
+            *reinterpret_cast<u4_t *>(lds + kmaj_off(row0 + 32 * i, chunk)) = v;
+        }
+    }
+};
+
+template <> struct StagerBf16<kLayOuterVec /* unit stride along the rows */> {
+    static constexpr bool OUTER = true;
+    int64_t fix_off;
+    u4_t regs[4];
+    int chunk, line0;
+    __device__ __forceinline__ void init(const int64_t *__restrict__ tab_rows, int64_t r0, int64_t R, int t)
+    {
+        chunk = t & 15;
+        line0 = t >> 4;
+        const int64_t r = r0 + 8 * chunk;
+        fix_off = tab_rows[r < R ? r : R - 8];  // R is a multiple of 8 whenever this layout is chosen
+    }
+    __device__ __forceinline__ void issue(const unsigned short *__restrict__ base, const int64_t *__restrict__ tab_k,
+                                          int64_t k0, int64_t)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            regs[i] = *reinterpret_cast<const u4_t *>(base + fix_off + tab_k[k0 + line0 + 16 * i]);
+    }
+    __device__ __forceinline__ void commit(unsigned char *lds, int64_t k0, int64_t K)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u4_t v = regs[i];
+            if (k0 + line0 + 16 * i >= K) v = u4_t{0, 0, 0, 0};
+            *reinterpret_cast<u4_t *>(lds + outer_off(line0 + 16 * i, chunk)) = v;
+        }
+    }
+};
+
+template <> struct StagerBf16<kLayScalar /* element loads, any strides */> {
+    // The fallback when no 16-byte vectors are legal (odd extents, odd strides, unaligned
+    // base).  A thread owns 8 rows x 4 k of the tile; sixteen neighbouring lanes run along
+    // whichever of the two dimensions is contiguous in memory.  Element pairs share a
+    // register while the tile waits for the MFMAs of the previous one.
+    static constexpr bool OUTER = false;
+    int64_t fix_off[8];
+    unsigned regs[16];
+    int row0, kk0;
+    __device__ __forceinline__ void init(const int64_t *__restrict__ tab_rows, int64_t r0, int64_t R, int t)
+    {
+        const bool rows_fast = R > 1 && tab_rows[1] - tab_rows[0] == 1;
+        row0 = rows_fast ? (t & 15) : (t >> 4);
+        kk0 = rows_fast ? (t >> 4) : (t & 15);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t r = r0 + row0 + 16 * i;
+            fix_off[i] = tab_rows[r < R ? r : R - 1];
+        }
+    }
+    __device__ __forceinline__ void issue(const unsigned short *__restrict__ base, const int64_t *__restrict__ tab_k,
+                                          int64_t k0, int64_t)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t ko = tab_k[k0 + kk0 + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                const unsigned lo = base[fix_off[i] + ko], hi = base[fix_off[i + 1] + ko];
+                regs[4 * j + i / 2] = lo | (hi << 16);
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(unsigned char *lds, int64_t k0, int64_t K)
+    {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kk0 + 16 * j;
+            const bool live = k0 + k < K;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned pair = regs[4 * j + i / 2];
+                const unsigned short v = (unsigned short)((i & 1) ? (pair >> 16) : (pair & 0xFFFFu));
+                *reinterpret_cast<unsigned short *>(lds + kmaj_off(row0 + 16 * i, k >> 3) + 2 * (k & 7)) =
+                    live ? v : (unsigned short)0;
+            }
+        }
+    }
+};
+
+// MFMA operand of the 16 rows (columns) starting at r16 for k-step ks (32 k) of a tile image
+template <bool OUTER> __device__ __forceinline__ bf8_t fragment(const unsigned char *img, int r16, int ks, int lane)
+{
+    if constexpr (!OUTER) {
+        const int row = r16 + (lane & 15);
+        return *reinterpret_cast<const bf8_t *>(img + kmaj_off(row, 4 * ks + (lane >> 4)));
+    } else {
+    // lane 4q+p of a 16-lane group names line q, rows 4p..4p+3 of the block; it receives the
+    // four lines of row (lane & 15)
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int k = 32 * ks + 8 * g + q;
+    const int ch = (r16 >> 3) + (p >> 1);
+    typedef s4_t __attribute__((address_space(3))) * lds_s4_ptr;
+    const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_s4_ptr)(const_cast<unsigned char *>(img) + outer_off(k, ch) + 8 * (p & 1)));
+    const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (lds_s4_ptr)(const_cast<unsigned char *>(img) + outer_off(k + 4, ch) + 8 * (p & 1)));
+    const s8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf8_t, both);
+    }
+}
+
+template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_kernel(const GemmParams p)
+{
+    typedef StagerBf16<LA> SA;
+    typedef StagerBf16<LB> SB;
+    constexpr int TM = 4, TN = 4;  // 16 x 16 accumulators per wave: a 64 x 64 block of C
+
+    // [buffer][A image | B image]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kImageBytes];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+
+    // Block -> tile: blocks b and b+8 share an XCD (and its L2), so every XCD gets a contiguous
+    // run of tile ids, walked in groups of `group` tile rows to share A and B panels.
+    int sid;
+    {
+        const int bid = blockIdx.x, nblk = p.nbm * p.nbn;
+        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int width = p.group * p.nbn;
+    const int first_m = (sid / width) * p.group;
+    const int gsz = min(p.nbm - first_m, p.group);
+    const int tm = first_m + (sid % width) % gsz;
+    const int tn = (sid % width) / gsz;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int bz = blockIdx.y;
+
+    const unsigned short *A = static_cast<const unsigned short *>(p.A) + p.bat_a[bz];
+    const unsigned short *B = static_cast<const unsigned short *>(p.B) + p.bat_b[bz];
+    unsigned short *C = static_cast<unsigned short *>(p.C) + p.bat_c[bz];
+
+    SA sa;
+    SB sb;
+    sa.init(p.row_a, m0, p.M, t);
+    sb.init(p.col_b, n0, p.N, t);
+
+    f4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)((p.K + BK - 1) / BK);
+    sa.issue(A, p.k_a, 0, p.K);
+    sb.issue(B, p.k_b, 0, p.K);
+    sa.commit(smem, 0, p.K);
+    sb.commit(smem + kImageBytes, 0, p.K);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned char *ia = smem + (kt & 1) * 2 * kImageBytes;
+        const unsigned char *ib = ia + kImageBytes;
+        unsigned char *na = smem + ((kt & 1) ^ 1) * 2 * kImageBytes;
+        const bool more = kt + 1 < nk;
+        const int64_t k_next = (int64_t)(kt + 1) * BK;
+        if (more) {
+            sa.issue(A, p.k_a, k_next, p.K);
+            sb.issue(B, p.k_b, k_next, p.K);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf8_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = fragment<SA::OUTER>(ia, wm0 + 16 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = fragment<SB::OUTER>(ib, wn0 + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            sa.commit(na, k_next, p.K);
+            sb.commit(na + kImageBytes, k_next, p.K);
+        }
+        __syncthreads();
+    }
+
+    // Epilogue.  Accumulator register r of lane l: row 4 (l >> 4) + r, column l & 15.
+    const float alpha = (float)p.alpha, beta = (float)p.beta;
+    const int frow = lane & 15;
+    if (p.c_vec >= 4) {
+        // 8-byte stores: a 4 x 4 transpose inside each quad leaves lane q with four
+        // neighbouring columns of row register q
+        typedef gemm_detail::Traits<float> Tr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int64_t m = m0 + wm0 + 16 * i + Tr::cvec_row(lane, 0);
+            const int64_t ro = p.row_c[m < p.M ? m : 0];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int64_t n = n0 + wn0 + 16 * j + (frow & ~3);
+                const f4_t v = Tr::cvec(acc[i][j], lane, 0);  // every lane takes part in the exchange
+                if (m < p.M && n < p.N) {                      // N is a multiple of the vector length
+                    u2_t *dst = reinterpret_cast<u2_t *>(C + ro + p.col_c[n]);
+                    float o[4] = {alpha * v[0], alpha * v[1], alpha * v[2], alpha * v[3]};
+                    if (beta != 0.f) {
+                        const u2_t old = *dst;
+                        o[0] += beta * bf16_to_f32((unsigned short)(old[0] & 0xFFFFu));
+                        o[1] += beta * bf16_to_f32((unsigned short)(old[0] >> 16));
+                        o[2] += beta * bf16_to_f32((unsigned short)(old[1] & 0xFFFFu));
+                        o[3] += beta * bf16_to_f32((unsigned short)(old[1] >> 16));
+                    }
+                    u2_t w;
+                    w[0] = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+                    w[1] = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+                    *dst = w;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int64_t n = n0 + wn0 + 16 * j + frow;
+        const int64_t co = p.col_c[n < p.N ? n : 0];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + wm0 + 16 * i + 4 * (lane >> 4) + r;
+                if (m < p.M && n < p.N) {
+                    unsigned short *dst = C + p.row_c[m] + co;
+                    float o = alpha * acc[i][j][r];
+                    if (beta != 0.f) o += beta * bf16_to_f32(*dst);
+                    *dst = f32_to_bf16(o);
+                }
+            }
+        }
+    }
+}
+
+template <int LA, int LB> hipError_t launch_one(const GemmParams &p, hipStream_t stream)
+{
+    GemmParams q = p;
+    q.nbm = (int)((p.M + BM - 1) / BM);
+    q.nbn = (int)((p.N + BN - 1) / BN);
+    if ((int64_t)q.nbm * q.nbn > 0x7FFFFFFF) return hipErrorInvalidValue;
+    if (q.group < 1) q.group = 1;
+    hipLaunchKernelGGL((gemm_bf16_kernel<LA, LB>), dim3((unsigned)(q.nbm * q.nbn), (unsigned)p.batch, 1), dim3(NT), 0,
+                       stream, q);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm_bf16(int la, int lb, const GemmParams &p, hipStream_t stream)
+{
+    if (la < 0 || la > 2 || lb < 0 || lb > 2) return hipErrorInvalidValue;
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
+#define CTC_CASE(A_, B_) \
+    case A_ * 3 + B_: return launch_one<A_, B_>(p, stream);
+    switch (la * 3 + lb) {
+        CTC_CASE(0, 0) CTC_CASE(0, 1) CTC_CASE(0, 2) CTC_CASE(1, 0) CTC_CASE(1, 1) CTC_CASE(1, 2)
+        CTC_CASE(2, 0) CTC_CASE(2, 1) CTC_CASE(2, 2)
+    default: return hipErrorInvalidValue;
+    }
+#undef CTC_CASE
+}
+
+}  // namespace ctc

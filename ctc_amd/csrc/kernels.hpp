@@ -47,6 +47,10 @@ hipError_t schedule_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, 
 hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
                        const GemmSchedule &schedule, void *workspace, hipStream_t stream);
 
+// bf16 operands and result, f32 accumulation (gemm_bf16_kernels.hip): one 128 x 128 x 64 tile shape,
+// no split-K; schedule fields of `p` are filled by the launcher.
+hipError_t launch_gemm_bf16(int layout_a, int layout_b, const GemmParams &p, hipStream_t stream);
+
 // Skinny contraction C(m,n) = sum_k A(m,k) B(k,n) for M <= 16: streams B once and C once.
 // transpose == 0: n is the fused N index, B(k,n) = B[k_b[k] + nb[n]], C(m,n) = C[row_c[m] + nc[n]]
 //                 with nb = col_b, nc = col_c and X = N.

@@ -126,6 +126,10 @@ void choose_tile(Plan &p)
         if (atoi(force) == 128) { t.bm = 128; t.bn = 128; }
     }
     t.bk = 16;
+    if (p.dtype == kBF16) {
+        // the bf16 kernel has one tile shape
+        t.bm = 128; t.bn = 128; t.bk = 64;
+    }
     t.threads = 256;
     t.group = 8;
     p.tile = t;
@@ -299,7 +303,7 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
     p.kernel = kKernelGemm;
     const bool c_unit_in_n = c_unit >= 0 && p.modes[c_unit].cls != kBatch && p.modes[c_unit].cls != kContracted;
     const bool b_unit_in_n = b_unit >= 0 && std::find(p.ex_n.begin(), p.ex_n.end(), b_unit) != p.ex_n.end();
-    if (p.M <= kSkinnyMaxM && p.M * p.K <= kSkinnyMaxMK && p.N >= 4096 && c_unit_in_n && b_unit_in_n) {
+    if (dtype != kBF16 && p.M <= kSkinnyMaxM && p.M * p.K <= kSkinnyMaxMK && p.N >= 4096 && c_unit_in_n && b_unit_in_n) {
         const int vb = vector_width(p, gb_modes, gb, b_unit, vmax);
         const int vc = vector_width(p, p.c_modes, sc, c_unit, vmax);
         if (vb == vmax && vc == vmax) {

@@ -1,0 +1,166 @@
+"""Parity of the bf16 contraction path (bf16 operands and result, f32 accumulation inside
+v_mfma_f32_16x16x32_bf16) with the CPU oracle (f64 accumulation, one rounding to bf16).
+
+Tolerance: max |C_gpu - C_ref| <= 8e-3 * max |C_ref|.  One bf16 rounding of the result is
+worth up to 2^-8 = 3.9e-3 of the element; the f32 accumulation error can move a sum across a
+rounding boundary, so two correctly computed results can differ by one bf16 ulp."""
+import numpy as np
+import pytest
+import torch
+
+import ctc_amd
+
+pytestmark = pytest.mark.gpu
+
+TOL = 8e-3
+BF16 = 2
+
+
+def _to_dev(u16, dev):
+    return torch.from_numpy(u16.view(np.int16)).to(dev).view(torch.bfloat16)
+
+
+def _to_host(t):
+    return t.view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+def _sizes(spec, ext):
+    ins, outm = spec.split("->")
+    la, lb = ins.split(",")
+    n = lambda s: int(np.prod([ext[c] for c in s])) if s else 1  # noqa: E731
+    return n(la), n(lb), n(outm)
+
+
+def _check(oracle, got_u16, want_u16):
+    got = oracle.bf16_to_f32(got_u16).astype(np.float64)
+    want = oracle.bf16_to_f32(want_u16).astype(np.float64)
+    assert np.isfinite(got).all()
+    err = np.abs(got - want).max()
+    scale = max(np.abs(want).max(), 1e-300)
+    assert err <= TOL * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+CASES = [
+    # name, spec, extents, expected (layout_a, layout_b) or None
+    ("nn_kvec_outer", "ak,kb->ab", dict(a=256, b=256, k=128), ("k_vec", "outer_vec")),
+    ("nt_kvec_kvec", "ak,bk->ab", dict(a=200, b=136, k=72), ("k_vec", "k_vec")),
+    ("tn_outer_outer", "ka,kb->ab", dict(a=136, b=264, k=40), ("outer_vec", "outer_vec")),
+    ("tt_outer_kvec", "ka,bk->ab", dict(a=128, b=128, k=64), ("outer_vec", "k_vec")),
+    ("ragged_k_tail", "ak,kb->ab", dict(a=130, b=72, k=200), ("k_vec", "outer_vec")),
+    ("odd_everything_scalar", "ak,kb->ab", dict(a=67, b=45, k=77), ("scalar", "scalar")),
+    ("odd_tn_scalar", "ka,kb->ab", dict(a=67, b=45, k=77), ("scalar", "scalar")),
+    ("scalar_a_vec_b", "ak,kb->ab", dict(a=64, b=64, k=50), ("scalar", "outer_vec")),
+    ("c_transposed", "ak,kb->ba", dict(a=72, b=136, k=24), None),
+    ("k_shorter_than_a_vector", "ak,kb->ab", dict(a=64, b=64, k=2), None),
+    ("single_element", "ak,kb->ab", dict(a=1, b=1, k=1), None),
+    ("outer_product", "a,b->ab", dict(a=70, b=136), None),
+    ("matvec", "ak,k->a", dict(a=300, k=72), None),
+    ("batched", "zak,zkb->zab", dict(z=5, a=40, b=72, k=24), None),
+    ("batch_fastest", "akz,kbz->abz", dict(z=6, a=20, b=24, k=10), None),
+    ("ccsd_16", "aeim,ebmj->abij", dict(a=16, b=16, i=16, j=16, e=16, m=16), ("k_vec", "outer_vec")),
+    ("ccsd_ragged", "aeim,ebmj->abij", dict(a=13, b=11, i=10, j=14, e=7, m=6), None),
+    ("six_index", "adij,bcdk->abcijk", dict(a=6, b=5, c=4, i=6, j=8, k=8, d=16), None),
+    ("adversarial_modes", "dkca,bk->abcd", dict(a=32, b=8, c=12, d=32, k=8), None),
+    ("long_k", "ak,bk->ab", dict(a=128, b=128, k=4096), ("k_vec", "k_vec")),
+]
+
+
+@pytest.mark.parametrize("name,spec,ext,layouts", CASES, ids=[c[0] for c in CASES])
+def test_bf16_against_oracle(cuda, oracle, name, spec, ext, layouts):
+    na, nb, nc = _sizes(spec, ext)
+    A = oracle.fill(na, 0xC7C0A, BF16)
+    B = oracle.fill(nb, 0xC7C0B, BF16)
+    plan = ctc_amd.Plan(spec, ext, "bf16")
+    s = plan.summary()
+    assert s["kernel"] == "mfma_gemm" and tuple(s["tile"]) == (128, 128, 64)
+    if layouts is not None:
+        assert (s["layout_a"], s["layout_b"]) == layouts
+    dC = torch.full((nc,), float("nan"), dtype=torch.bfloat16, device=cuda)
+    plan.execute(_to_dev(A, cuda), _to_dev(B, cuda), dC)
+    _check(oracle, _to_host(dC), oracle.contract(spec, ext, A, B, dtype=BF16))
+
+
+def test_bf16_golden_vector(cuda, oracle, golden):
+    """The committed numpy.einsum samples of the bf16 case."""
+    n = 0
+    for c in golden["cases"]:
+        if c["dtype"] != "bf16":
+            continue
+        na, nb, nc = _sizes(c["spec"], c["extents"])
+        A = oracle.fill(na, c["seed_a"], BF16)
+        B = oracle.fill(nb, c["seed_b"], BF16)
+        dC = torch.full((nc,), float("nan"), dtype=torch.bfloat16, device=cuda)
+        ctc_amd.Plan(c["spec"], c["extents"], "bf16").execute(_to_dev(A, cuda), _to_dev(B, cuda), dC)
+        got = oracle.bf16_to_f32(_to_host(dC)).astype(np.float64)
+        scale = float.fromhex(c["max_abs"])
+        for i, hx in c["samples"]:
+            assert abs(float(got[i]) - float.fromhex(hx)) <= TOL * scale, (c["name"], i)
+        n += 1
+    assert n >= 1
+
+
+@pytest.mark.parametrize("spec,ext", [
+    ("ak,kb->ab", dict(a=200, b=136, k=72)),            # 8-byte stores of C
+    ("ak,kb->ab", dict(a=67, b=45, k=77)),              # element stores
+])
+def test_bf16_alpha_beta(cuda, oracle, spec, ext):
+    na, nb, nc = _sizes(spec, ext)
+    A = oracle.fill(na, 0xC7C0A, BF16)
+    B = oracle.fill(nb, 0xC7C0B, BF16)
+    C0 = oracle.fill(nc, 99, BF16)
+    dC = _to_dev(C0.copy(), cuda)
+    ctc_amd.Plan(spec, ext, "bf16").execute(_to_dev(A, cuda), _to_dev(B, cuda), dC, alpha=0.5, beta=-1.5)
+    want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=0.5, beta=-1.5, dtype=BF16)
+    _check(oracle, _to_host(dC), want)
+
+
+def test_bf16_unaligned_bases_fall_back_to_element_access(cuda, oracle):
+    spec, ext = "ak,kb->ab", dict(a=136, b=72, k=64)
+    na, nb, nc = _sizes(spec, ext)
+    A = oracle.fill(na + 1, 5, BF16)
+    B = oracle.fill(nb + 1, 6, BF16)
+    want = oracle.contract(spec, ext, A[1:].copy(), B[1:].copy(), dtype=BF16)
+    plan = ctc_amd.Plan(spec, ext, "bf16")
+    assert plan.summary()["layout_a"] == "k_vec" and plan.summary()["vec_c"] == 8
+    buf = torch.full((nc + 1,), float("nan"), dtype=torch.bfloat16, device=cuda)
+    plan.execute(_to_dev(A, cuda)[1:], _to_dev(B, cuda)[1:], buf[1:])
+    _check(oracle, _to_host(buf[1:].contiguous()), want)
+    assert torch.isnan(buf[0])
+
+
+def test_bf16_exact_on_small_integers(cuda):
+    """Integer-valued operands: every product and sum is exact in f32 and the results fit bf16,
+    so the result must equal the integer contraction bit for bit (catches operand-map mistakes
+    that a tolerance would hide).  B is asymmetric on purpose."""
+    m, n, k = 192, 160, 96
+    g = torch.Generator().manual_seed(7)
+    A = torch.randint(-2, 3, (m, k), generator=g).to(torch.float32)
+    B = torch.randint(-1, 2, (k, n), generator=g).to(torch.float32)
+    want = A.double() @ B.double()
+    assert want.abs().max() < 256  # integers below 2^8 are exact in bf16
+    for spec, a, b in (("ak,kb->ab", A, B), ("ka,kb->ab", A.t().contiguous(), B),
+                       ("ak,bk->ab", A, B.t().contiguous()), ("ka,bk->ab", A.t().contiguous(), B.t().contiguous())):
+        dA = a.to(cuda).to(torch.bfloat16).reshape(-1)
+        dB = b.to(cuda).to(torch.bfloat16).reshape(-1)
+        dC = torch.full((m * n,), float("nan"), dtype=torch.bfloat16, device=cuda)
+        ctc_amd.Plan(spec, dict(a=m, b=n, k=k), "bf16").execute(dA, dB, dC)
+        assert torch.equal(dC.double().cpu().reshape(m, n), want), spec
+
+
+def test_bf16_linearity_at_size(cuda):
+    """2048^3: contract(2A, B) == 2 contract(A, B) exactly (power-of-two scaling commutes with
+    every rounding), and a row block recomputed in f64 by torch agrees within tolerance."""
+    n = 2048
+    dA = torch.empty(n * n, dtype=torch.bfloat16, device=cuda)
+    dB = torch.empty(n * n, dtype=torch.bfloat16, device=cuda)
+    ctc_amd.fill(dA, 0xC7C0A)
+    ctc_amd.fill(dB, 0xC7C0B)
+    plan = ctc_amd.Plan("ak,kb->ab", dict(a=n, b=n, k=n), "bf16")
+    dC = torch.empty(n * n, dtype=torch.bfloat16, device=cuda)
+    dC2 = torch.empty_like(dC)
+    plan.execute(dA, dB, dC)
+    plan.execute(dA * 2, dB, dC2)
+    assert torch.equal(dC2, dC * 2)
+    rows = dA.reshape(n, n)[100:132].double() @ dB.reshape(n, n).double()
+    got = dC.reshape(n, n)[100:132].double()
+    assert (got - rows).abs().max() <= TOL * rows.abs().max()
