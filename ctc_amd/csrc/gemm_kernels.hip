@@ -190,12 +190,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
 #ifdef CTC_STAMPS
     unsigned long long st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_n = 0;
 #endif
-    // Every tile runs the same instruction stream: past the last tile the look-ahead
-    // loads re-read the operand's last k (the padded k tables keep them in bounds) and
-    // land in an LDS buffer nobody reads, which is cheaper than peeling the loop.
-    auto tile_step = [&](auto mask_t, int kt) {
-        constexpr bool HAS1 = true, HAS2 = true;
-        constexpr bool MASK = decltype(mask_t)::value;  // tile kt+1 may cross K
+    // Three instantiations, run in a straight line (loop, second-to-last tile, last tile):
+    // the last two tiles leave out what would reach past the end of K, so that a contraction
+    // with few K-tiles does not fetch two more tiles than it uses.
+    auto tile_step = [&](auto mask_t, auto next_t, auto issue_t, int kt) {
+        constexpr bool HAS1 = decltype(next_t)::value;   // there is a tile kt+1: commit it, read its first fragments
+        constexpr bool HAS2 = decltype(issue_t)::value;  // there is a tile kt+2: issue its global loads
+        constexpr bool MASK = decltype(mask_t)::value;   // tile kt+1 may cross K
         const int cur = kt & 1;
         const T *la = smem + cur * STAGE_ELEMS;
         const T *lb = la + SA::LDS_ELEMS;
@@ -275,12 +276,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
 #endif
     {
         int kt = 0;
-        for (; kt + 2 < nk; ++kt) tile_step(std::false_type(), kt);
+        for (; kt + 2 < nk; ++kt) tile_step(std::false_type(), std::true_type(), std::true_type(), kt);
         if (kt + 1 < nk) {
-            tile_step(std::true_type(), kt);  // commits the last tile, which may cross K
+            // commits the last tile, which may cross K
+            tile_step(std::true_type(), std::true_type(), std::false_type(), kt);
             ++kt;
         }
-        tile_step(std::false_type(), kt);
+        tile_step(std::false_type(), std::false_type(), std::false_type(), kt);
     }
 #ifdef CTC_STAMPS
     CTC_STAMP(st_loop1);
@@ -349,7 +351,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     vec_t v = Tr::cvec(acc[i][j], lane, s) * alpha;
+#ifdef CTC_EXP_NOSTORE
+                    if (rvoff != kNoOffset && cvoff[j] != kNoOffset && v[0] == (T)1.2345e30) {
+#else
                     if (rvoff != kNoOffset && cvoff[j] != kNoOffset) {
+#endif
                         vec_t *dst = reinterpret_cast<vec_t *>(C + rvoff + cvoff[j]);
                         if (WITH_BETA) v += *dst * beta;
                         *dst = v;
@@ -529,8 +535,12 @@ hipError_t dispatch_layouts(int la, int lb, const GemmParams &p, GemmSchedule *s
     case A_ * 3 + B_:                                                                                          \
         return sch_out ? schedule_one<T, A_, B_, BM, BN>(p, sch_out) : launch_one<T, A_, B_, BM, BN>(p, *sch_in, ws, stream);
     switch (la * 3 + lb) {
+#ifdef CTC_EXP_ONE  // diagnostic builds of a single instantiation, e.g. -DCTC_EXP_ONE="CTC_CASE(1,1)" (tools/build_variant.sh)
+        CTC_EXP_ONE
+#else
         CTC_CASE(0, 0) CTC_CASE(0, 1) CTC_CASE(0, 2) CTC_CASE(1, 0) CTC_CASE(1, 1) CTC_CASE(1, 2)
         CTC_CASE(2, 0) CTC_CASE(2, 1) CTC_CASE(2, 2)
+#endif
     default: return hipErrorInvalidValue;
     }
 #undef CTC_CASE
