@@ -33,6 +33,12 @@ def hand_cases():
         ("zero_qualities", ref, "TTTTTTTT", [0] * 8, 4),
         ("original_zero", ref, ref[10:20], [25] * 10, 0),
         ("all_mismatch", "AAAAAAAAAAAA", "CCCC", [3, 4, 5, 6], 4),
+        # quality bytes above 127 are negative in the reference's signed arithmetic
+        ("quality_above_127", "ACGTACGTACGTACGTACGT", "ACTTAC", [30, 30, 200, 30, 30, 30], 8),
+        ("quality_above_127_negative_total", "AAAAAAAAAAAAAAAA", "CACA", [250, 10, 250, 10], 5),
+        # the original alignment hangs past the end, offsets left of it still hang, others do not
+        ("hanging_left_offsets", ref, ref[-12:-4] + "GGGGGGGG", [7] * 16, len(ref) - 8),
+        ("long_read_many_steps", ref * 3, (ref * 3)[17:17 + 61], [(i * 7) % 41 for i in range(61)], 40),
     ]
     return out
 

@@ -132,6 +132,56 @@ def test_gpu_matches_oracle_on_seeded_batches(cuda, kw):
     assert np.array_equal(index, want_index)
 
 
+def _awkward_batch(ref_len=(90, 260), n_regions=6):
+    """Seeded batch with everything the fast path must hand over or survive: quality bytes above
+    127 (negative in the reference), bytes above 127 and other non-bases in reads and consensuses,
+    original alignments that hang past the end of the consensus."""
+    b = ofastr.make_batch(seed=77, n_regions=n_regions, max_consensus=4, reads=(4, 12), read_len=52, ref_len=ref_len)
+    rng = np.random.default_rng(5)
+    rs = b["read_stride"]
+    n_reads = b["read_len"].size
+    q = b["quals"].reshape(n_reads, rs)
+    seq = b["read_seq"].reshape(n_reads, rs)
+    for g in range(0, n_reads, 3):                      # every third read: a few negative qualities
+        q[g, rng.integers(0, 52, size=3)] = rng.integers(128, 256, size=3)
+    for g in range(1, n_reads, 4):                      # non-bases, some with bit 7 set
+        seq[g, rng.integers(0, 52, size=4)] = np.array([0x80, 0xFF, ord("N"), ord("-")], dtype=np.uint8)
+    ref = b["ref"]
+    ref[rng.integers(0, ref.size, size=ref.size // 40)] = 0x80
+    ref[rng.integers(0, ref.size, size=ref.size // 40)] = 0xC1
+    # hanging original alignments: allowed up to the consensus length (shortest consensus of the region)
+    cons = 0
+    read_off = 0
+    for t in range(b["n_consensus"].size):
+        shortest = int(b["ref_lens"][cons:cons + b["n_consensus"][t]].min())
+        for g in range(read_off, read_off + b["alt_reads"][t], 2):
+            b["original_alignment"][g] = shortest - int(rng.integers(0, 30))
+        cons += b["n_consensus"][t]
+        read_off += b["alt_reads"][t]
+    return b
+
+
+@pytest.mark.skipif(not ofastr.reference_available(), reason="oracle/_ref/libfastr_ref.so not built")
+def test_oracle_matches_reference_live_on_the_awkward_batch():
+    b = _awkward_batch()
+    score, index = ofastr.best_offsets(b)
+    for j, (r, rd, q, o) in enumerate(ofastr.pair_iter(b)):
+        assert ofastr.reference_find_best_offset(r, rd, q, o) == (int(index[j]), int(score[j])), j
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(ref_len=(8300, 8600), n_regions=2)], ids=["staged", "beyond_lds"])
+def test_gpu_matches_oracle_on_the_awkward_batch(cuda, kw):
+    from ctc_amd import fastr
+    b = _awkward_batch(**kw)
+    want_score, want_index = ofastr.best_offsets(b)
+    if not kw:
+        assert (want_score < 0).any()  # negative totals do occur
+    score, index = fastr.best_offsets(b, cuda)
+    assert np.array_equal(score, want_score)
+    assert np.array_equal(index, want_index)
+
+
 @pytest.mark.gpu
 def test_gpu_empty_batch(cuda):
     import torch
