@@ -29,6 +29,18 @@
 #include <type_traits>
 #include <vector>
 
+// K-tile depth and the shape of the large tile; overridable for diagnostic builds
+// (tools/build_variant.sh), e.g. -DCTC_GEMM_BIG_BN=64 -DCTC_GEMM_BK=8.
+#ifndef CTC_GEMM_BK
+#define CTC_GEMM_BK 16
+#endif
+#ifndef CTC_GEMM_BIG_BM
+#define CTC_GEMM_BIG_BM 128
+#endif
+#ifndef CTC_GEMM_BIG_BN
+#define CTC_GEMM_BIG_BN 128
+#endif
+
 namespace ctc {
 
 namespace {
@@ -453,7 +465,7 @@ constexpr int kMinChunkTiles = 8;
 template <typename T, int LA, int LB, int BM, int BN>
 hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
 {
-    constexpr int BK = 16, WM = 2, WN = 2;
+    constexpr int BK = CTC_GEMM_BK, WM = 2, WN = 2;
     GemmSchedule s;
     s.nbm = (int)((p.M + BM - 1) / BM);
     s.nbn = (int)((p.N + BN - 1) / BN);
@@ -486,7 +498,7 @@ hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
 template <typename T, int LA, int LB, int BM, int BN>
 hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
-    constexpr int BK = 16, WM = 2, WN = 2;
+    constexpr int BK = CTC_GEMM_BK, WM = 2, WN = 2;
     GemmParams q = p;
     q.nbm = sch.nbm;
     q.nbn = sch.nbn;
@@ -550,8 +562,10 @@ template <typename T>
 hipError_t dispatch_tiles(int la, int lb, int bm, int bn, const GemmParams &p, GemmSchedule *sch_out,
                           const GemmSchedule *sch_in, void *ws, hipStream_t stream)
 {
-    if (bm == 128 && bn == 128) return dispatch_layouts<T, 128, 128>(la, lb, p, sch_out, sch_in, ws, stream);
+    if (bm == 128 && bn == 128) return dispatch_layouts<T, CTC_GEMM_BIG_BM, CTC_GEMM_BIG_BN>(la, lb, p, sch_out, sch_in, ws, stream);
+#ifndef CTC_EXP_ONE
     if (bm == 64 && bn == 64) return dispatch_layouts<T, 64, 64>(la, lb, p, sch_out, sch_in, ws, stream);
+#endif
     return hipErrorInvalidValue;
 }
 
@@ -561,7 +575,9 @@ hipError_t dispatch(int dtype, int la, int lb, int bm, int bn, const GemmParams 
     if (la < 0 || la > 2 || lb < 0 || lb > 2) return hipErrorInvalidValue;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
     if (dtype == 0) return dispatch_tiles<double>(la, lb, bm, bn, p, sch_out, sch_in, ws, stream);
+#ifndef CTC_EXP_ONE
     if (dtype == 1) return dispatch_tiles<float>(la, lb, bm, bn, p, sch_out, sch_in, ws, stream);
+#endif
     return hipErrorInvalidValue;
 }
 
