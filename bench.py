@@ -1,13 +1,19 @@
 """Headline benchmark: fp64 CCSD-style contraction C[a,b,i,j] = sum_em A[a,e,i,m] * B[e,b,m,j]
 (BASELINE.json configs[1]) on MI355X through the C ABI of libctc_tc.so.
 
-  python bench.py --gpus N --steps K --warmup W [--extent 96]
+  python bench.py --gpus N --steps K --warmup W [--extent 96] [--shard free|contracted]
 
 A step is one whole contraction with operands already resident in HBM.  With
 N > 1 (one process per GPU under torch.distributed.run) the contraction grows
 along the free index `a` (extent = N * extent): every rank owns one slab of A
 and of C, B is replicated, no collective touches the data path ("weak" scaling).
 Rank 0 prints one JSON line.
+
+--shard contracted (BASELINE configs[3], second variant) keeps the contraction at all extents
+`extent` and splits the contracted index e over the ranks instead ("strong" scaling): every
+rank holds 1/N of A and of B, computes a full-size partial C and the partials are summed by
+one RCCL reduce-scatter, after which every rank owns |C|/N.  The step time includes the
+collective.
 """
 import argparse
 import json
@@ -59,6 +65,73 @@ def measured_traffic(extent, kernel_summary):
     return t["per_launch_bytes"]["total_corrected"]
 
 
+def bench_contracted(args, world, rank, dev, backend):
+    """Contracted index e split over the ranks, partial results summed by one reduce-scatter."""
+    from ctc_amd.sharded import ShardedContraction
+    n = args.extent
+    ext = dict(a=n, b=n, i=n, j=n, e=n, m=n)
+    sc = ShardedContraction(SPEC, ext, "f64", "e", rank, world)
+    # rank-local packed slabs: A[a, e/p, i, m], B[e/p, b, m, j]; synthetic, one stream per rank
+    A = torch.empty(sc.local_numel("a"), dtype=torch.float64, device=dev)
+    B = torch.empty(sc.local_numel("b"), dtype=torch.float64, device=dev)
+    ctc_amd.fill(A, SEED_A + rank * 0x100000000)
+    ctc_amd.fill(B, SEED_B + rank * 0x100000000)
+    partial = torch.empty(sc.full_c_numel(), dtype=torch.float64, device=dev)
+    C = torch.empty(sc.full_c_numel() // world, dtype=torch.float64, device=dev)
+    sc.plan.prepare()
+
+    def step():
+        sc.execute(A, B, C, scratch=partial)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed load so the chip holds its clocks: kernel only (a timed loop may not hold a
+    # collective, the ranks would call it different numbers of times)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm:
+        sc.plan.execute(A, B, partial)
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    kernel_ms = sc.plan.time(A, B, partial, warmup=1, iters=max(2, args.steps // 2))
+    flops_job = 2 * n ** 6
+    value = flops_job / (elapsed / args.steps) * 1e-12
+    if rank == 0:
+        achieved = sc.plan.flops / (kernel_ms * 1e-3) * 1e-12
+        print(json.dumps({
+            "metric": "achieved TFLOP/s per contraction (fp64, C[a,b,i,j]=A[a,e,i,m]*B[e,b,m,j])",
+            "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (splitmix64 uniform[-1,1), generated in HBM)",
+            "config": {"workload": "BASELINE configs[3] variant: abij=aeim,ebmj fp64, all extents %d, contracted "
+                                   "index e split over %d GPUs, one reduce-scatter of C (%d MB) per step"
+                                   % (n, world, sc.full_c_numel() * 8 // 1000000),
+                       "collective": "reduce_scatter_tensor" if backend == "nccl" else "gloo all_reduce + slice",
+                       "flops_per_step": flops_job,
+                       "pct_of_fp64_mfma_peak": round(100.0 * value / (PEAK_FP64_MFMA_TFLOPS * world), 2)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_kernel<double> on one rank's slab (collective not included)",
+                         "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": sc.plan.flops},
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,6 +140,7 @@ def main():
     ap.add_argument("--extent", type=int, default=96, help="extent of every mode (64..96 in BASELINE)")
     ap.add_argument("--cpu-extent", type=int, default=96, help="extent of the CPU-oracle sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--shard", choices=("free", "contracted"), default="free")
     ap.add_argument("--prewarm", type=float, default=0.1, help="seconds of untimed load before the warm-up steps")
     args = ap.parse_args()
 
@@ -89,6 +163,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run" % (args.gpus, world))
 
     n = args.extent
+    if args.shard == "contracted":
+        return bench_contracted(args, world, rank, dev, backend)
     full_ext = dict(a=n * world, b=n, i=n, j=n, e=n, m=n)
     full = ctc_amd.Plan(SPEC, full_ext, "f64")
     plan, off_a, off_b, off_c = full.shard("a", rank, world)

@@ -79,7 +79,12 @@ class ShardedContraction:
         if reduce == "all_reduce":
             run(self.plan, A, B, C, alpha, 0.0)
             if self.world > 1:
-                dist.all_reduce(C, op=dist.ReduceOp.SUM, group=group)
+                if C.is_cuda and dist.get_backend(group) == "gloo":
+                    host = C.cpu()
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                    C.copy_(host)
+                else:
+                    dist.all_reduce(C, op=dist.ReduceOp.SUM, group=group)
             return C
         if n % self.world:
             raise ValueError("reduce_scatter needs |C| divisible by the world size")
@@ -88,10 +93,12 @@ class ShardedContraction:
         if self.world == 1:
             C.copy_(partial)
         elif dist.get_backend(group) == "gloo":
-            # gloo has no reduce_scatter: same result through all_reduce + slice (CPU tests only)
-            dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+            # gloo has no reduce_scatter: same result through all_reduce + slice, staged through
+            # host memory when the partial lives on a GPU (CPU tests and one-GPU rehearsals only)
+            host = partial if not partial.is_cuda else partial.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
             chunk = n // self.world
-            C.copy_(partial[self.rank * chunk:(self.rank + 1) * chunk])
+            C.copy_(host[self.rank * chunk:(self.rank + 1) * chunk])
         else:
             dist.reduce_scatter_tensor(C, partial, op=dist.ReduceOp.SUM, group=group)
         return C
