@@ -19,7 +19,16 @@
 // memory as int16, one 128-byte line per step.  The start cell follows the reference's two
 // scans (last column top to bottom with >=, then last row with the closer-to-diagonal rule),
 // and the back-track walks the stored entries exactly as calculateCigar does.
+//
+// Score type: double as in the reference, or int32 when the four weights are integers of
+// modest size.  Every score is then an integer that both types represent exactly, every
+// comparison has the same outcome, and the int32 cell costs about half the instructions
+// (one register per value for the selects and the DPP hand-over).  The "no gap yet" and
+// "minus infinity" sentinels only need to stay below every reachable score.
 #include "kernels.hpp"
+
+#include <climits>
+#include <cstdlib>
 
 namespace ctc {
 
@@ -36,8 +45,29 @@ __device__ __forceinline__ double shr1_d(double x)
     const int hi = __double2hiint(x), lo = __double2loint(x);
     return __hiloint2double(shr1_i(hi, hi), shr1_i(lo, lo));
 }
+__device__ __forceinline__ int shr1_s(int x) { return shr1_i(x, x); }
+__device__ __forceinline__ double shr1_s(double x) { return shr1_d(x); }
+__device__ __forceinline__ int xor_s(int x, int off) { return __shfl_xor(x, off); }
+__device__ __forceinline__ double xor_s(double x, int off)
+{
+    return __hiloint2double(__shfl_xor(__double2hiint(x), off), __shfl_xor(__double2loint(x), off));
+}
 
-__global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
+template <typename S> struct SwLimits;
+template <> struct SwLimits<double> {
+    static __device__ __forceinline__ double cutoff() { return -1e100; }   // MATRIX_MIN_CUTOFF of the reference
+    static __device__ __forceinline__ double no_gap() { return -1.0e40; }
+    static __device__ __forceinline__ double lowest() { return -1.0e300; }
+};
+template <> struct SwLimits<int> {
+    // weights are at most kSwMaxIntWeight in magnitude and a path has at most 65534 steps, so
+    // scores stay within +-6.6e7; no_gap may drift down by one extension per row or column
+    static __device__ __forceinline__ int cutoff() { return INT_MIN; }
+    static __device__ __forceinline__ int no_gap() { return -(1 << 29); }
+    static __device__ __forceinline__ int lowest() { return INT_MIN; }
+};
+
+template <typename S> __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char sw_lds[];
     const int lane = threadIdx.x & 63;
@@ -49,12 +79,12 @@ __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
     // per-wave LDS: boundary score / vertical gap / gap length per column, last-row scores,
     // read bases, collected CIGAR operations
     const int L1 = p.max_read_len + 1;
-    const size_t per_wave = (size_t)L1 * (3 * sizeof(double) + sizeof(int)) + (size_t)((p.max_read_len + 7) & ~7) +
+    const size_t per_wave = (size_t)L1 * (3 * sizeof(S) + sizeof(int)) + (size_t)((p.max_read_len + 7) & ~7) +
                             (size_t)p.max_ops * (sizeof(int) + 1) + 16;
     unsigned char *base = sw_lds + (size_t)wave * ((per_wave + 15) & ~(size_t)15);
-    double *s_up = reinterpret_cast<double *>(base);
-    double *s_bgv = s_up + L1;
-    double *s_last = s_bgv + L1;
+    S *s_up = reinterpret_cast<S *>(base);
+    S *s_bgv = s_up + L1;
+    S *s_last = s_bgv + L1;
     int *s_gsv = reinterpret_cast<int *>(s_last + L1);
     int *s_oplen = s_gsv + L1;
     unsigned char *s_read = reinterpret_cast<unsigned char *>(s_oplen + p.max_ops);
@@ -68,14 +98,14 @@ __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
     }
     const unsigned char *a = p.ref + p.ref_off[pair];
     const unsigned char *b = p.reads + pair * (long long)p.read_stride;
-    const double wm = p.w_match, wx = p.w_mismatch, wo = p.w_open, we = p.w_extend;
-    const double kCutoff = -1e100, kNoGap = -1.0e40;
+    const S wm = (S)p.w_match, wx = (S)p.w_mismatch, wo = (S)p.w_open, we = (S)p.w_extend;
+    const S kCutoff = SwLimits<S>::cutoff(), kNoGap = SwLimits<S>::no_gap();
 
     for (int j = lane; j <= m; j += 64) {
-        s_up[j] = 0.0;
+        s_up[j] = (S)0;
         s_bgv[j] = kNoGap;
         s_gsv[j] = 0;
-        s_last[j] = 0.0;
+        s_last[j] = (S)0;
         if (j < m) s_read[j] = b[j];
     }
 
@@ -83,7 +113,7 @@ __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
     short *bt = p.bt + (size_t)pair_local * p.bt_per_pair;
 
     // first scan of the start cell, kept on the fly: best of the last column with later rows winning ties
-    double col_best = 0.0;
+    S col_best = (S)0;
     int col_best_i = 0;
 
     const int nrb = (n + 63) / 64;
@@ -91,15 +121,15 @@ __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
         const int i = 64 * rb + lane + 1;
         const bool row_ok = i <= n;
         const unsigned a_base = row_ok ? a[i - 1] : 0x100u;
-        double val = 0.0, up_prev = 0.0, bgh = kNoGap;
+        S val = (S)0, up_prev = (S)0, bgh = kNoGap;
         int gsh = 0;
-        double out_val = 0.0, out_bgv = kNoGap, my_last = 0.0;
+        S out_val = (S)0, out_bgv = kNoGap, my_last = (S)0;
         int out_gsv = 0, out_base = 0;
         bool have_last = false;
         short *bt_blk = bt + (size_t)rb * T * 64 + lane;
         const int steps = m + 63;
         for (int t = 1; t <= steps; ++t) {
-            double r_up = shr1_d(out_val), r_bgv = shr1_d(out_bgv);
+            S r_up = shr1_s(out_val), r_bgv = shr1_s(out_bgv);
             int r_gsv = shr1_i(out_gsv, out_gsv), r_base = shr1_i(out_base, out_base);
             if (lane == 0 && t <= m) {
                 r_up = s_up[t];
@@ -109,9 +139,9 @@ __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
             }
             const int j = t - lane;
             if (j >= 1 && j <= m) {
-                const double step_diag = up_prev + ((unsigned)r_base == a_base ? wm : wx);
-                double prev_gap = r_up + wo;
-                double bgv = r_bgv + we;
+                const S step_diag = up_prev + ((unsigned)r_base == a_base ? wm : wx);
+                S prev_gap = r_up + wo;
+                S bgv = r_bgv + we;
                 int gsv;
                 if (prev_gap > bgv) { bgv = prev_gap; gsv = 1; }
                 else gsv = r_gsv + 1;
@@ -119,7 +149,7 @@ __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
                 bgh += we;
                 if (prev_gap > bgh) { bgh = prev_gap; gsh = 1; }
                 else gsh += 1;
-                double v;
+                S v;
                 int tr;
                 if (bgv > bgh) {
                     if (bgv > step_diag) { v = bgv; tr = gsv; }
@@ -148,11 +178,11 @@ __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
         }
         // last column of this block: max score, the largest row among equals; ">=" against the
         // running best (earlier blocks are earlier rows)
-        double bs = have_last ? my_last : -1.0e300;
+        S bs = have_last ? my_last : SwLimits<S>::lowest();
         int bi = have_last ? i : 0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const double os = __hiloint2double(__shfl_xor(__double2hiint(bs), off), __shfl_xor(__double2loint(bs), off));
+            const S os = xor_s(bs, off);
             const int oi = __shfl_xor(bi, off);
             if (os > bs || (os == bs && oi > bi)) { bs = os; bi = oi; }
         }
@@ -161,10 +191,10 @@ __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
 
     // ---- start cell (calculateCigar, first part); every lane runs the same scalar walk ----
     int p1 = col_best_i, p2 = col_best_i > 0 ? m : 0;
-    double maxscore = col_best;
+    S maxscore = col_best;
     int segment_length = 0;
     for (int j = 1; j <= m; ++j) {
-        const double s = s_last[j];
+        const S s = s_last[j];
         const int d1 = n - j, d2 = p1 - p2;
         if ((s > maxscore || s == maxscore) && (d1 < 0 ? -d1 : d1) < (d2 < 0 ? -d2 : d2)) {
             p1 = n;
@@ -223,12 +253,24 @@ __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel(const SwParams p)
 
 }  // namespace
 
-size_t sw_lds_bytes(int max_read_len, int max_ops)
+static size_t sw_lds_bytes_for(int max_read_len, int max_ops, size_t score_bytes)
 {
     const size_t L1 = (size_t)max_read_len + 1;
-    const size_t per_wave = L1 * (3 * sizeof(double) + sizeof(int)) + (size_t)((max_read_len + 7) & ~7) +
+    const size_t per_wave = L1 * (3 * score_bytes + sizeof(int)) + (size_t)((max_read_len + 7) & ~7) +
                             (size_t)max_ops * (sizeof(int) + 1) + 16;
     return (size_t)kSwWaves * ((per_wave + 15) & ~(size_t)15);
+}
+
+size_t sw_lds_bytes(int max_read_len, int max_ops) { return sw_lds_bytes_for(max_read_len, max_ops, sizeof(double)); }
+
+// int32 scores are exact when every weight is an integer of modest size
+constexpr double kSwMaxIntWeight = 1000.0;
+static bool sw_integer_weights(const SwParams &p)
+{
+    const double w[4] = {p.w_match, p.w_mismatch, p.w_open, p.w_extend};
+    for (double x : w)
+        if (!(x == (double)(long long)x) || x > kSwMaxIntWeight || x < -kSwMaxIntWeight) return false;
+    return true;
 }
 
 size_t sw_bt_elems_per_pair(int max_ref_len, int max_read_len)
@@ -239,10 +281,15 @@ size_t sw_bt_elems_per_pair(int max_ref_len, int max_read_len)
 hipError_t launch_sw(const SwParams &p, hipStream_t stream)
 {
     if (p.n_pairs <= 0) return hipSuccess;
-    const size_t lds = sw_lds_bytes(p.max_read_len, p.max_ops);
+    static const bool force_double = getenv("CTC_SW_FORCE_DOUBLE") != nullptr;  // A/B runs
+    const bool ints = !force_double && sw_integer_weights(p);
+    const size_t lds = sw_lds_bytes_for(p.max_read_len, p.max_ops, ints ? sizeof(int) : sizeof(double));
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((p.n_pairs + kSwWaves - 1) / kSwWaves);
-    hipLaunchKernelGGL(sw_kernel, dim3(blocks), dim3(64 * kSwWaves), lds, stream, p);
+    if (ints)
+        hipLaunchKernelGGL(sw_kernel<int>, dim3(blocks), dim3(64 * kSwWaves), lds, stream, p);
+    else
+        hipLaunchKernelGGL(sw_kernel<double>, dim3(blocks), dim3(64 * kSwWaves), lds, stream, p);
     return hipGetLastError();
 }
 
