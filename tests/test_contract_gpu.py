@@ -292,3 +292,23 @@ def test_headline_size_properties(cuda, oracle):
     dC2 = torch.empty_like(dC)
     plan.execute(dA * 2.0, dB, dC2)
     assert torch.equal(dC2, dC * 2.0)
+
+
+def test_offsets_beyond_2_31_elements(cuda):
+    """C with 2.6e9 elements (10.5 GB of f32): row and column offsets are 64-bit all the way to the
+    stores.  Rows on both sides of the 2^31-element line are recomputed in f64."""
+    a, b, k = 65536, 40000, 8
+    dA = torch.empty(a * k, dtype=torch.float32, device=cuda)
+    dB = torch.empty(k * b, dtype=torch.float32, device=cuda)
+    ctc_amd.fill(dA, 0xC7C0A)
+    ctc_amd.fill(dB, 0xC7C0B)
+    dC = torch.empty(a * b, dtype=torch.float32, device=cuda)
+    ctc_amd.Plan("ak,kb->ab", dict(a=a, b=b, k=k), "f32").execute(dA, dB, dC)
+    A = dA.reshape(a, k).double()
+    B = dB.reshape(k, b).double()
+    for r in (0, 1, 53686, 53687, 53688, a - 1):   # 53687 * 40000 < 2^31 <= 53688 * 40000
+        want = A[r] @ B
+        got = dC[r * b:(r + 1) * b].double()
+        assert (got - want).abs().max() <= 1e-5 * want.abs().max(), r
+    del dC
+    torch.cuda.empty_cache()
