@@ -111,6 +111,31 @@ def test_config1_through_the_unchanged_engine(tmp_path, oracle, ext):
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,code,tol", [("f32", 1, 1e-5), ("bf16", 2, 8e-3)])
+def test_other_element_types_through_the_unchanged_engine(tmp_path, oracle, dtype, code, tol):
+    """--dtype travels through the plugin's template; files hold the raw element type."""
+    if not os.path.exists(ENGINE):
+        pytest.fail("oracle/_ref/execute_engine missing: run oracle/build_ref.sh where /root/reference exists")
+    ext = dict(a=32, b=48, c=16, d=24)
+    A = oracle.fill(ext["a"] * ext["d"] * ext["c"], 0xC7C0A, code)
+    B = oracle.fill(ext["d"] * ext["b"], 0xC7C0B, code)
+    A.tofile(tmp_path / "A.bin")
+    B.tofile(tmp_path / "B.bin")
+    extents = ",".join("%s=%d" % kv for kv in ext.items())
+    run = subprocess.run([ENGINE, eb.ENGINE_ROOT, "plugin", "contract", "--spec", "adc,db=abc", "--extents", extents,
+                          "--dtype", dtype, "--input_a", str(tmp_path / "A.bin"), "--input_b", str(tmp_path / "B.bin"),
+                          "--output_c", str(tmp_path / "C.bin")], capture_output=True, text=True, cwd=str(tmp_path))
+    assert os.path.exists(tmp_path / "C.bin"), run.stdout + run.stderr
+    want = oracle.contract("adc,db->abc", ext, A, B, dtype=code)
+    got = np.fromfile(tmp_path / "C.bin", dtype=want.dtype)
+    assert got.shape == want.shape
+    if dtype == "bf16":
+        got, want = oracle.bf16_to_f32(got), oracle.bf16_to_f32(want)
+    got, want = got.astype(np.float64), want.astype(np.float64)
+    assert np.abs(got - want).max() <= tol * np.abs(want).max()
+
+
 def _engine_workflow_dry_run(workflow, params, cwd):
     argv = [ENGINE, eb.ENGINE_ROOT, "--test", "workflow", workflow]
     for k, v in params.items():
