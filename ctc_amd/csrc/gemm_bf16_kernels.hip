@@ -19,10 +19,13 @@
 //                  vectors along the rows; a fragment is two ds_read_b64_tr_b16 (the
 //                  hardware transposes a block of 4 k x 16 rows per 16 lanes), conflict-free
 //                  because the two blocks a 32-lane half reads are 8 lines apart.
-// Staging is global -> registers -> LDS with two LDS buffers: the loads of tile t+1 are in
-// flight while tile t feeds the MFMAs, one barrier per tile; two workgroups share a CU.
+// Staging uses two LDS buffers: the loads of tile t+1 are in flight while tile t feeds the
+// MFMAs, one barrier per tile; two workgroups share a CU.  Tiles inside K go global -> LDS by
+// DMA (global_load_lds_dwordx4), the K tail and element-load operands through registers.
 #include "gemm_device.hpp"
 #include "kernels.hpp"
+
+#include <type_traits>
 
 namespace ctc {
 
@@ -63,14 +66,26 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_a
 // as zero.
 template <int LAY> struct StagerBf16;
 
+// LDS-DMA (global_load_lds_dwordx4): lane l of a wave instruction writes 16 bytes at the wave's
+// LDS base + 16 l, so a thread must fetch the chunk whose image slot is 16 t + 4096 i: the
+// swizzle is applied to the SOURCE chunk (which is the same for all four of a thread's
+// passes, because the XOR term repeats every 16 rows / 16 lines).
+__device__ __forceinline__ void dma16(const void *src, unsigned char *lds_wave_base)
+{
+    typedef __attribute__((address_space(1))) const void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
 template <> struct StagerBf16<0 /* unit stride along K */> {
     static constexpr bool OUTER = false;
+    static constexpr bool DIRECT = true;
     int64_t fix_off[4];
     u4_t regs[4];
     int chunk, row0;
     __device__ __forceinline__ void init(const int64_t *__restrict__ tab_rows, int64_t r0, int64_t R, int t)
     {
-        chunk = t & 7;
+        chunk = (t & 7) ^ ((t >> 4) & 7);  // lands in slot t & 7 of its row
         row0 = t >> 3;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -84,6 +99,16 @@ template <> struct StagerBf16<0 /* unit stride along K */> {
         const int64_t ko = tab_k[k0 + 8 * chunk];
 #pragma unroll
         for (int i = 0; i < 4; ++i) regs[i] = *reinterpret_cast<const u4_t *>(base + fix_off[i] + ko);
+    }
+    // Whole tile inside K: global -> LDS without passing through registers.  The k offsets come
+    // from prefetch(), called one tile earlier: an ordinary load issued while a DMA is in flight
+    // would make the compiler drain the DMA before the load's first use.
+    int64_t koff;
+    __device__ __forceinline__ void prefetch(const int64_t *__restrict__ tab_k, int64_t k0) { koff = tab_k[k0 + 8 * chunk]; }
+    __device__ __forceinline__ void direct(const unsigned short *__restrict__ base, unsigned char *img, int wave)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(base + fix_off[i] + koff, img + 4096 * i + 1024 * wave);
     }
     __device__ __forceinline__ void commit(unsigned char *lds, int64_t k0, int64_t K)
     {
@@ -99,13 +124,14 @@ template <> struct StagerBf16<0 /* unit stride along K */> {
 
 template <> struct StagerBf16<kLayOuterVec /* unit stride along the rows */> {
     static constexpr bool OUTER = true;
+    static constexpr bool DIRECT = true;
     int64_t fix_off;
     u4_t regs[4];
     int chunk, line0;
     __device__ __forceinline__ void init(const int64_t *__restrict__ tab_rows, int64_t r0, int64_t R, int t)
     {
-        chunk = t & 15;
         line0 = t >> 4;
+        chunk = (t & 15) ^ (((line0 & 3) << 2) | ((line0 >> 2) & 3));  // lands in slot t & 15 of its line
         const int64_t r = r0 + 8 * chunk;
         fix_off = tab_rows[r < R ? r : R - 8];  // R is a multiple of 8 whenever this layout is chosen
     }
@@ -115,6 +141,17 @@ template <> struct StagerBf16<kLayOuterVec /* unit stride along the rows */> {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             regs[i] = *reinterpret_cast<const u4_t *>(base + fix_off + tab_k[k0 + line0 + 16 * i]);
+    }
+    int64_t koff[4];
+    __device__ __forceinline__ void prefetch(const int64_t *__restrict__ tab_k, int64_t k0)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) koff[i] = tab_k[k0 + line0 + 16 * i];
+    }
+    __device__ __forceinline__ void direct(const unsigned short *__restrict__ base, unsigned char *img, int wave)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(base + fix_off + koff[i], img + 4096 * i + 1024 * wave);
     }
     __device__ __forceinline__ void commit(unsigned char *lds, int64_t k0, int64_t K)
     {
@@ -133,8 +170,11 @@ template <> struct StagerBf16<kLayScalar /* element loads, any strides */> {
     // whichever of the two dimensions is contiguous in memory.  Element pairs share a
     // register while the tile waits for the MFMAs of the previous one.
     static constexpr bool OUTER = false;
+    static constexpr bool DIRECT = false;
     int64_t fix_off[8];
     unsigned regs[16];
+    __device__ __forceinline__ void prefetch(const int64_t *, int64_t) {}
+    __device__ __forceinline__ void direct(const unsigned short *, unsigned char *, int) {}
     int row0, kk0;
     __device__ __forceinline__ void init(const int64_t *__restrict__ tab_rows, int64_t r0, int64_t R, int t)
     {
@@ -245,10 +285,36 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
         for (int j = 0; j < TN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (int)((p.K + BK - 1) / BK);
-    sa.issue(A, p.k_a, 0, p.K);
-    sb.issue(B, p.k_b, 0, p.K);
-    sa.commit(smem, 0, p.K);
-    sb.commit(smem + kImageBytes, 0, p.K);
+    // A tile that lies inside K goes global -> LDS by DMA (vector layouts); the last tile of a
+    // K that is not a multiple of 64 needs its tail zeroed and goes through registers, as do
+    // operands read element by element.
+    auto is_direct = [&](auto &st, int64_t k0) {
+        typedef std::remove_reference_t<decltype(st)> S;
+        return S::DIRECT && k0 + BK <= p.K;
+    };
+    auto stage_begin = [&](auto &st, const unsigned short *base, const int64_t *tab_k, int64_t k0, unsigned char *img) {
+        if (is_direct(st, k0)) st.direct(base, img, wave);
+        else st.issue(base, tab_k, k0, p.K);
+    };
+    auto stage_end = [&](auto &st, int64_t k0, unsigned char *img) {
+        if (!is_direct(st, k0)) st.commit(img, k0, p.K);
+    };
+    // k offsets of a DMA tile are fetched one tile ahead (the k tables are padded past K, but
+    // only by one tile)
+    auto prefetch = [&](int kt) {
+        const int64_t k0 = (int64_t)kt * BK;
+        if (kt < nk) {
+            if (is_direct(sa, k0)) sa.prefetch(p.k_a, k0);
+            if (is_direct(sb, k0)) sb.prefetch(p.k_b, k0);
+        }
+    };
+    prefetch(0);
+    stage_begin(sa, A, p.k_a, 0, smem);
+    stage_begin(sb, B, p.k_b, 0, smem + kImageBytes);
+    prefetch(1);
+    stage_end(sa, 0, smem);
+    stage_end(sb, 0, smem + kImageBytes);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA counts as an outstanding load
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -258,8 +324,10 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
         const bool more = kt + 1 < nk;
         const int64_t k_next = (int64_t)(kt + 1) * BK;
         if (more) {
-            sa.issue(A, p.k_a, k_next, p.K);
-            sb.issue(B, p.k_b, k_next, p.K);
+            // the other buffer was last read before the barrier that ended the previous tile
+            stage_begin(sa, A, p.k_a, k_next, na);
+            stage_begin(sb, B, p.k_b, k_next, na + kImageBytes);
+            prefetch(kt + 2);
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
@@ -275,9 +343,10 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            sa.commit(na, k_next, p.K);
-            sb.commit(na + kImageBytes, k_next, p.K);
+            stage_end(sa, k_next, na);
+            stage_end(sb, k_next, na + kImageBytes);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
