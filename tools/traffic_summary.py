@@ -21,7 +21,7 @@ def counters(directory, counter):
                 out["fixup"].append(float(value))
             elif "gemm_kernel" in name:
                 out["gemm"].append(float(value))
-                out["gemm_name"] = name.split("::")[-1].split("(")[0]
+                out["gemm_name"] = name[name.index("gemm_kernel"):].split("(")[0]
             elif "copyBuffer" in name:
                 out["copy"].append(float(value))
     return out
