@@ -329,18 +329,27 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
             stage_begin(sb, B, p.k_b, k_next, na + kImageBytes);
             prefetch(kt + 2);
         }
+        // Both k-steps' fragments are requested up front, in k-step order, so that the second
+        // half of the reads lands while the first sixteen MFMAs run; the order is pinned, the
+        // compiler only adds the counted waits.
+        static_assert(BK == 64, "two k-steps per tile");
+        bf8_t fa[2][TM], fb[2][TN];
 #pragma unroll
-        for (int ks = 0; ks < BK / 32; ++ks) {
-            bf8_t fa[TM], fb[TN];
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = fragment<SA::OUTER>(ia, wm0 + 16 * i, ks, lane);
+            for (int i = 0; i < TM; ++i) fa[ks][i] = fragment<SA::OUTER>(ia, wm0 + 16 * i, ks, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = fragment<SB::OUTER>(ib, wn0 + 16 * j, ks, lane);
+            for (int j = 0; j < TN; ++j) fb[ks][j] = fragment<SB::OUTER>(ib, wn0 + 16 * j, ks, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) {
             stage_end(sa, k_next, na);
