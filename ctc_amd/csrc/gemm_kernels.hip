@@ -442,6 +442,17 @@ __global__ void __launch_bounds__(256) splitk_fixup_kernel(const GemmParams p)
     }
 }
 
+// K-tile depth: 16 by default; the large f32 tile takes 32 (the same bytes per tile as f64 at 16:
+// an f32 MFMA holds the pipe half as long, so a barrier per 16 k came twice as often in time).
+template <typename T, int BM> constexpr int tile_bk()
+{
+#ifdef CTC_GEMM_BK_F32
+    return (sizeof(T) == 4 && BM == 128) ? CTC_GEMM_BK_F32 : CTC_GEMM_BK;
+#else
+    return (sizeof(T) == 4 && BM == 128) ? 32 : CTC_GEMM_BK;
+#endif
+}
+
 // workgroup slots of the current device for one kernel instantiation (cached per device)
 template <typename K> int resident_slots(K kernel, int threads)
 {
@@ -465,7 +476,7 @@ constexpr int kMinChunkTiles = 8;
 template <typename T, int LA, int LB, int BM, int BN>
 hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
 {
-    constexpr int BK = CTC_GEMM_BK, WM = 2, WN = 2;
+    constexpr int BK = tile_bk<T, BM>(), WM = 2, WN = 2;
     GemmSchedule s;
     s.nbm = (int)((p.M + BM - 1) / BM);
     s.nbn = (int)((p.N + BN - 1) / BN);
@@ -498,7 +509,7 @@ hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
 template <typename T, int LA, int LB, int BM, int BN>
 hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
-    constexpr int BK = CTC_GEMM_BK, WM = 2, WN = 2;
+    constexpr int BK = tile_bk<T, BM>(), WM = 2, WN = 2;
     GemmParams q = p;
     q.nbm = sch.nbm;
     q.nbn = sch.nbn;
@@ -574,8 +585,10 @@ hipError_t dispatch(int dtype, int la, int lb, int bm, int bn, const GemmParams 
 {
     if (la < 0 || la > 2 || lb < 0 || lb > 2) return hipErrorInvalidValue;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
+#if !defined(CTC_EXP_ONE) || !defined(CTC_EXP_F32)
     if (dtype == 0) return dispatch_tiles<double>(la, lb, bm, bn, p, sch_out, sch_in, ws, stream);
-#ifndef CTC_EXP_ONE
+#endif
+#if !defined(CTC_EXP_ONE) || defined(CTC_EXP_F32)
     if (dtype == 1) return dispatch_tiles<float>(la, lb, bm, bn, p, sch_out, sch_in, ws, stream);
 #endif
     return hipErrorInvalidValue;
