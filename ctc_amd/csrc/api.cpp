@@ -271,12 +271,6 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     if (la != ctc::kLayoutScalar && (reinterpret_cast<uintptr_t>(g.A) & 15)) la = ctc::kLayoutScalar;
     if (lb != ctc::kLayoutScalar && (reinterpret_cast<uintptr_t>(g.B) & 15)) lb = ctc::kLayoutScalar;
 
-    if (p.dtype == ctc::kBF16) {
-        hipError_t be = ctc::launch_gemm_bf16(la, lb, g, stream);
-        if (be != hipSuccess) return fail_hip(be, "bf16 contraction kernel launch");
-        return CTC_TC_OK;
-    }
-
     ctc::GemmSchedule sch;
     hipError_t e = ctc::schedule_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, &sch);
     if (e != hipSuccess) return fail_hip(e, "contraction schedule");
@@ -427,7 +421,7 @@ int ctc_tc_plan_prepare(ctc_tc_plan *plan)
     rc = upload_tables(plan, device, t);
     if (rc) return rc;
     const ctc::Plan &p = plan->plan;
-    if (p.kernel == ctc::kKernelGemm && p.dtype != ctc::kBF16 && p.batch <= 65535) {
+    if (p.kernel == ctc::kKernelGemm && p.batch <= 65535) {
         // the split-K workspace the vector-load variant will ask for
         ctc::GemmParams g;
         g.M = p.M; g.N = p.N; g.K = p.K;

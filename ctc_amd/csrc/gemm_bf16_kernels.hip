@@ -25,6 +25,7 @@
 #include "gemm_device.hpp"
 #include "kernels.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace ctc {
@@ -253,13 +254,25 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
 
-    // Block -> tile: blocks b and b+8 share an XCD (and its L2), so every XCD gets a contiguous
-    // run of tile ids, walked in groups of `group` tile rows to share A and B panels.
-    int sid;
+    // Block -> item.  Blocks b and b+8 share an XCD (and its L2), so every XCD gets a contiguous
+    // run of tile ids, walked in groups of `group` tile rows to share A and B panels.  The
+    // first dp_tiles tiles run whole; the tiles of the last, partly filled round of the grid
+    // are cut along K into `split` chunks whose f32 accumulators go to a workspace
+    // (splitk_fixup_bf16_kernel sums them in chunk order).
+    int sid, chunk = 0;
+    bool partial = false;
     {
-        const int bid = blockIdx.x, nblk = p.nbm * p.nbn;
-        const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-        sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int bid = blockIdx.x;
+        if (bid < p.dp_tiles) {
+            const int nblk = p.dp_tiles;
+            const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+            sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        } else {
+            const int rel = bid - p.dp_tiles;
+            sid = p.dp_tiles + rel / p.split;
+            chunk = rel % p.split;
+            partial = true;
+        }
     }
     const int width = p.group * p.nbn;
     const int first_m = (sid / width) * p.group;
@@ -284,7 +297,9 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (int)((p.K + BK - 1) / BK);
+    const int nk_total = (int)((p.K + BK - 1) / BK);
+    const int kt_first = partial ? (int)((int64_t)chunk * nk_total / p.split) : 0;
+    const int nk = partial ? (int)((int64_t)(chunk + 1) * nk_total / p.split) : nk_total;  // one past the last K-tile
     // A tile that lies inside K goes global -> LDS by DMA (vector layouts); the last tile of a
     // K that is not a multiple of 64 needs its tail zeroed and goes through registers, as do
     // operands read element by element.
@@ -308,19 +323,23 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
             if (is_direct(sb, k0)) sb.prefetch(p.k_b, k0);
         }
     };
-    prefetch(0);
-    stage_begin(sa, A, p.k_a, 0, smem);
-    stage_begin(sb, B, p.k_b, 0, smem + kImageBytes);
-    prefetch(1);
-    stage_end(sa, 0, smem);
-    stage_end(sb, 0, smem + kImageBytes);
+    {
+        const int64_t k_first = (int64_t)kt_first * BK;
+        prefetch(kt_first);
+        stage_begin(sa, A, p.k_a, k_first, smem);
+        stage_begin(sb, B, p.k_b, k_first, smem + kImageBytes);
+        prefetch(kt_first + 1);
+        stage_end(sa, k_first, smem);
+        stage_end(sb, k_first, smem + kImageBytes);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA counts as an outstanding load
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned char *ia = smem + (kt & 1) * 2 * kImageBytes;
+    for (int kt = kt_first; kt < nk; ++kt) {
+        const int buf = (kt - kt_first) & 1;
+        const unsigned char *ia = smem + buf * 2 * kImageBytes;
         const unsigned char *ib = ia + kImageBytes;
-        unsigned char *na = smem + ((kt & 1) ^ 1) * 2 * kImageBytes;
+        unsigned char *na = smem + (buf ^ 1) * 2 * kImageBytes;
         const bool more = kt + 1 < nk;
         const int64_t k_next = (int64_t)(kt + 1) * BK;
         if (more) {
@@ -362,6 +381,19 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
     // Epilogue.  Accumulator register r of lane l: row 4 (l >> 4) + r, column l & 15.
     const float alpha = (float)p.alpha, beta = (float)p.beta;
     const int frow = lane & 15;
+    if (partial) {
+        // raw f32 accumulators of this K chunk: tile-shaped slab [BM][BN] in the workspace
+        float *slab = static_cast<float *>(p.ws) + ((int64_t)(sid - p.dp_tiles) * p.split + chunk) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm0 + 16 * i + 4 * (lane >> 4) + r;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) slab[row * BN + wn0 + 16 * j + frow] = acc[i][j][r];
+            }
+        return;
+    }
     if (p.c_vec >= 4) {
         // 8-byte stores: a 4 x 4 transpose inside each quad leaves lane q with four
         // neighbouring columns of row register q
@@ -413,26 +445,128 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
     }
 }
 
-template <int LA, int LB> hipError_t launch_one(const GemmParams &p, hipStream_t stream)
+// Sums the K chunks of the split tiles in chunk order and writes C = alpha * sum + beta * C in bf16.
+// One workgroup per (tile, 16 rows); a thread owns two neighbouring columns.
+__global__ void __launch_bounds__(256) splitk_fixup_bf16_kernel(const GemmParams p)
+{
+    constexpr int ROWS = 16, VPR = BN / 2, RPP = 256 / VPR;  // column pairs per row, rows per pass
+    const int tile_rel = blockIdx.x / (BM / ROWS);
+    const int rblk = blockIdx.x % (BM / ROWS);
+    const int sid = p.dp_tiles + tile_rel;
+    const int width = p.group * p.nbn;
+    const int first_m = (sid / width) * p.group;
+    const int gsz = min(p.nbm - first_m, p.group);
+    const int tm = first_m + (sid % width) % gsz;
+    const int tn = (sid % width) / gsz;
+    const float *slab0 = static_cast<const float *>(p.ws) + (int64_t)tile_rel * p.split * (BM * BN);
+    unsigned short *C = static_cast<unsigned short *>(p.C);
+    const float alpha = (float)p.alpha, beta = (float)p.beta;
+    const int cv = threadIdx.x % VPR;
+    const int64_t n = (int64_t)tn * BN + 2 * cv;
+    const bool ok0 = n < p.N, ok1 = n + 1 < p.N;
+    const int64_t c0 = p.col_c[ok0 ? n : 0], c1 = p.col_c[ok1 ? n + 1 : 0];
+    for (int rr = threadIdx.x / VPR; rr < ROWS; rr += RPP) {
+        const int row = rblk * ROWS + rr;
+        const int64_t m = (int64_t)tm * BM + row;
+        if (m >= p.M) continue;
+        float s0 = 0.f, s1 = 0.f;
+        for (int c = 0; c < p.split; ++c) {
+            const float *src = slab0 + (int64_t)c * (BM * BN) + row * BN + 2 * cv;
+            s0 += src[0];
+            s1 += src[1];
+        }
+        const int64_t ro = p.row_c[m];
+        if (ok0) {
+            float v = alpha * s0;
+            if (beta != 0.f) v += beta * bf16_to_f32(C[ro + c0]);
+            C[ro + c0] = f32_to_bf16(v);
+        }
+        if (ok1) {
+            float v = alpha * s1;
+            if (beta != 0.f) v += beta * bf16_to_f32(C[ro + c1]);
+            C[ro + c1] = f32_to_bf16(v);
+        }
+    }
+}
+
+// workgroup slots of the current device (two workgroups per CU: 64 KB of LDS each)
+int bf16_slots()
+{
+    static int cache[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cache[dev] == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_bf16_kernel<0, 0>, NT, 0) != hipSuccess) return 0;
+        cache[dev] = cus * per_cu > 0 ? cus * per_cu : -1;
+    }
+    return cache[dev] > 0 ? cache[dev] : 0;
+}
+
+constexpr int kMinChunkTilesBf16 = 16;  // K-tiles (of 64) per chunk at least: shorter chunks cost more in the second launch than they save
+
+template <int LA, int LB> hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     GemmParams q = p;
-    q.nbm = (int)((p.M + BM - 1) / BM);
-    q.nbn = (int)((p.N + BN - 1) / BN);
-    if ((int64_t)q.nbm * q.nbn > 0x7FFFFFFF) return hipErrorInvalidValue;
+    q.nbm = sch.nbm;
+    q.nbn = sch.nbn;
+    q.dp_tiles = sch.dp_tiles;
+    q.split = sch.split;
+    q.ws = ws;
     if (q.group < 1) q.group = 1;
-    hipLaunchKernelGGL((gemm_bf16_kernel<LA, LB>), dim3((unsigned)(q.nbm * q.nbn), (unsigned)p.batch, 1), dim3(NT), 0,
-                       stream, q);
+    if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_bf16_kernel<LA, LB>), dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1),
+                       dim3(NT), 0, stream, q);
+    if (sch.tail_tiles > 0)
+        hipLaunchKernelGGL(splitk_fixup_bf16_kernel, dim3((unsigned)(sch.tail_tiles * (BM / 16))), dim3(256), 0, stream, q);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_gemm_bf16(int la, int lb, const GemmParams &p, hipStream_t stream)
+// Same policy as the f64/f32 kernel: tiles = q * slots + tail; the q full rounds run whole, each
+// tail tile is cut along K into floor(slots / tail) chunks.  Problems with fewer tiles than
+// slots are split entirely, which is what keeps medium-sized contractions on the whole chip
+// (this kernel has one tile shape).
+hipError_t schedule_gemm_bf16(const GemmParams &p, GemmSchedule *out)
+{
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
+    GemmSchedule s;
+    s.nbm = (int)((p.M + BM - 1) / BM);
+    s.nbn = (int)((p.N + BN - 1) / BN);
+    const int64_t tiles = (int64_t)s.nbm * s.nbn;
+    if (tiles > 0x7FFFFFFF) return hipErrorInvalidValue;
+    s.dp_tiles = (int)tiles;
+    s.split = 1;
+    s.tail_tiles = 0;
+    s.ws_bytes = 0;
+    static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
+    const int slots = bf16_slots();
+    const int nk = (int)((p.K + BK - 1) / BK);
+    if (!no_split && slots > 0 && p.batch == 1) {
+        const int tail = (int)(tiles % slots);
+        if (tail > 0) {
+            int f = slots / tail;
+            if (f > nk / kMinChunkTilesBf16) f = nk / kMinChunkTilesBf16;
+            if (f >= 2) {
+                s.tail_tiles = tail;
+                s.dp_tiles = (int)tiles - tail;
+                s.split = f;
+                s.ws_bytes = (size_t)tail * f * BM * BN * sizeof(float);
+            }
+        }
+    }
+    *out = s;
+    return hipSuccess;
+}
+
+hipError_t launch_gemm_bf16(int la, int lb, const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     if (la < 0 || la > 2 || lb < 0 || lb > 2) return hipErrorInvalidValue;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
 #define CTC_CASE(A_, B_) \
-    case A_ * 3 + B_: return launch_one<A_, B_>(p, stream);
+    case A_ * 3 + B_: return launch_one<A_, B_>(p, sch, ws, stream);
     switch (la * 3 + lb) {
         CTC_CASE(0, 0) CTC_CASE(0, 1) CTC_CASE(0, 2) CTC_CASE(1, 0) CTC_CASE(1, 1) CTC_CASE(1, 2)
         CTC_CASE(2, 0) CTC_CASE(2, 1) CTC_CASE(2, 2)

@@ -39,7 +39,7 @@ struct GemmSchedule {
     size_t ws_bytes = 0;  // workspace the launch needs (0: none)
 };
 
-// dtype: 0 f64, 1 f32.  layouts: see ctc_tc_layout.  bm/bn select the tile.
+// dtype: 0 f64, 1 f32, 2 bf16.  layouts: see ctc_tc_layout.  bm/bn select the tile.
 // Returns hipSuccess or the launch error; hipErrorInvalidValue for an
 // unsupported combination.
 hipError_t schedule_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
@@ -47,9 +47,11 @@ hipError_t schedule_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, 
 hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
                        const GemmSchedule &schedule, void *workspace, hipStream_t stream);
 
-// bf16 operands and result, f32 accumulation (gemm_bf16_kernels.hip): one 128 x 128 x 64 tile shape,
-// no split-K; schedule fields of `p` are filled by the launcher.
-hipError_t launch_gemm_bf16(int layout_a, int layout_b, const GemmParams &p, hipStream_t stream);
+// bf16 operands and result, f32 accumulation (gemm_bf16_kernels.hip): one 128 x 128 x 64 tile shape;
+// reached through schedule_gemm / launch_gemm with dtype 2.
+hipError_t schedule_gemm_bf16(const GemmParams &p, GemmSchedule *out);
+hipError_t launch_gemm_bf16(int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
+                            void *workspace, hipStream_t stream);
 
 // Skinny contraction C(m,n) = sum_k A(m,k) B(k,n) for M <= 16: streams B once and C once.
 // transpose == 0: n is the fused N index, B(k,n) = B[k_b[k] + nb[n]], C(m,n) = C[row_c[m] + nc[n]]

@@ -62,6 +62,11 @@ CASES = [
     ("six_index", "adij,bcdk->abcijk", dict(a=6, b=5, c=4, i=6, j=8, k=8, d=16), None),
     ("adversarial_modes", "dkca,bk->abcd", dict(a=32, b=8, c=12, d=32, k=8), None),
     ("long_k", "ak,bk->ab", dict(a=128, b=128, k=4096), ("k_vec", "k_vec")),
+    # fewer tiles than workgroup slots: every tile is cut along K, f32 partial sums, fix-up kernel
+    ("splitk_medium", "ak,kb->ab", dict(a=512, b=384, k=4096), ("k_vec", "outer_vec")),
+    ("splitk_ragged_k_tail", "ak,bk->ab", dict(a=250, b=201, k=3064), ("k_vec", "k_vec")),
+    ("splitk_scalar", "ak,kb->ab", dict(a=130, b=67, k=2221), ("scalar", "scalar")),
+    ("splitk_permuted", "aeim,ebmj->abij", dict(a=8, b=8, i=16, j=16, e=48, m=64), None),
 ]
 
 
@@ -102,6 +107,7 @@ def test_bf16_golden_vector(cuda, oracle, golden):
 @pytest.mark.parametrize("spec,ext", [
     ("ak,kb->ab", dict(a=200, b=136, k=72)),            # 8-byte stores of C
     ("ak,kb->ab", dict(a=67, b=45, k=77)),              # element stores
+    ("ak,kb->ab", dict(a=300, b=264, k=3072)),          # split along K: the fix-up kernel applies alpha and beta
 ])
 def test_bf16_alpha_beta(cuda, oracle, spec, ext):
     na, nb, nc = _sizes(spec, ext)
