@@ -125,8 +125,10 @@ __global__ void __launch_bounds__(64 * kWaves) fastr_kernel(const FastrParams p)
     int read_len = 0, orig = 0;
     bool signed_quals = false;
     if (active) {
-        read_len = p.read_len[g];
-        orig = p.original_alignment[g];
+        // device-side arguments cannot be checked by the host: keep them inside the read's slot
+        // and the consensus so that bad input gives a wrong score, not a stray access
+        read_len = min(max(p.read_len[g], 0), p.read_stride);
+        orig = max(p.original_alignment[g], 0);
         const unsigned char *rs = p.read_seq + g * p.read_stride;
         const unsigned char *qs = p.quals + g * p.read_stride;
         for (int i = lane; i < read_len + 8; i += 64) {
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(64 * kWaves) fastr_kernel_global(const FastrPa
     const unsigned char *ref = p.ref + w.ref_off;
     const int ref_len = w.ref_len;
     const long long g = (long long)w.first_read + wave;
-    const int read_len = p.read_len[g], orig = p.original_alignment[g];
+    const int read_len = min(max(p.read_len[g], 0), p.read_stride), orig = max(p.original_alignment[g], 0);
     const unsigned char *rd = p.read_seq + g * p.read_stride;
     const unsigned char *ql = p.quals + g * p.read_stride;
 

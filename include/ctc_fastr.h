@@ -23,7 +23,9 @@
  * d_* pointers are DEVICE memory, h_* pointers are HOST memory (the per-region counts are a
  * few hundred bytes; the library turns them into a work table and uploads it).  The call
  * enqueues on `stream` and returns; h_* arrays may be reused as soon as it returns.
- * original_alignment must lie in [0, ref_len] for every consensus of the read's region.
+ * original_alignment must lie in [0, ref_len] for every consensus of the read's region and
+ * read_len in [0, read_stride]; values outside are clamped on the device (negative to 0,
+ * read_len to read_stride), so bad input yields a meaningless score rather than a stray access.
  * Returns 0 or a negative ctc_tc_status (see ctc_tc.h); message in ctc_tc_last_error().
  */
 #ifndef CTC_FASTR_H
