@@ -11,8 +11,9 @@
 // (+ vertical, - horizontal, 0 diagonal).  Arithmetic is double, as in the reference.
 //
 // Mapping: one wave per pair.  The window is cut into blocks of 64 rows; in a block lane l owns
-// row 64*rb + l + 1 and walks the columns skewed by its lane number, so that at step t the wave
-// covers one anti-diagonal.  Everything a cell needs from the row above (score, the column's
+// row 64*rb + l + 1 and walks the columns skewed by its lane number, so that at every step the
+// wave covers one anti-diagonal; a lane that finishes its row goes straight on to its row of the
+// next block, so the blocks overlap and the skew is paid once per pair.  Everything a cell needs from the row above (score, the column's
 // running vertical gap and its length, the read base of the column) is handed from lane l to
 // lane l+1 by a whole-wave DPP shift per step; lane 0 takes it from a per-column boundary
 // array in LDS that lane 63 of the previous block left there.  Back-track entries go to global
@@ -112,81 +113,97 @@ template <typename S> __global__ void __launch_bounds__(64 * kSwWaves) sw_kernel
     const int T = p.max_read_len + 63;  // steps per row block in the back-track store
     short *bt = p.bt + (size_t)pair_local * p.bt_per_pair;
 
-    // first scan of the start cell, kept on the fly: best of the last column with later rows winning ties
-    S col_best = (S)0;
-    int col_best_i = 0;
-
+    // One continuous sweep over all row blocks.  Lane l enters row block rb at step rb * P + l + 1
+    // and spends P = max(m, 64) steps in it (the first m on columns 1..m), so a lane moves from
+    // the end of its row in one block straight into its row of the next block: the skew of 63
+    // steps is paid once per pair, not once per block.  P >= 64 makes sure lane 63 of block
+    // rb - 1 has left column j in the LDS boundary arrays before lane 0 of block rb reads it.
     const int nrb = (n + 63) / 64;
-    for (int rb = 0; rb < nrb; ++rb) {
-        const int i = 64 * rb + lane + 1;
-        const bool row_ok = i <= n;
-        const unsigned a_base = row_ok ? a[i - 1] : 0x100u;
-        S val = (S)0, up_prev = (S)0, bgh = kNoGap;
-        int gsh = 0;
-        S out_val = (S)0, out_bgv = kNoGap, my_last = (S)0;
-        int out_gsv = 0, out_base = 0;
-        bool have_last = false;
-        short *bt_blk = bt + (size_t)rb * T * 64 + lane;
-        const int steps = m + 63;
-        for (int t = 1; t <= steps; ++t) {
-            S r_up = shr1_s(out_val), r_bgv = shr1_s(out_bgv);
-            int r_gsv = shr1_i(out_gsv, out_gsv), r_base = shr1_i(out_base, out_base);
-            if (lane == 0 && t <= m) {
-                r_up = s_up[t];
-                r_bgv = s_bgv[t];
-                r_gsv = s_gsv[t];
-                r_base = s_read[t - 1];
+    const int P = m > 64 ? m : 64;
+    const int total = nrb * P + 63;
+    int j = 1 - lane;  // this lane's column in its current row; <= 0: not started yet
+    int rb = 0;
+    S val = (S)0, up_prev = (S)0, bgh = kNoGap;
+    int gsh = 0;
+    S out_val = (S)0, out_bgv = kNoGap;
+    int out_gsv = 0, out_base = 0;
+    S best_s = (S)0;  // best of the last column over this lane's rows, later rows win ties
+    int best_i = 0;
+    int i = lane + 1;
+    bool row_ok = i <= n;
+    unsigned a_base = row_ok ? a[i - 1] : 0x100u;
+    for (int step = 1; step <= total; ++step) {
+        S r_up = shr1_s(out_val), r_bgv = shr1_s(out_bgv);
+        int r_gsv = shr1_i(out_gsv, out_gsv), r_base = shr1_i(out_base, out_base);
+        const bool in_row = j >= 1 && j <= m && rb < nrb;
+        if (lane == 0 && in_row) {
+            r_up = s_up[j];
+            r_bgv = s_bgv[j];
+            r_gsv = s_gsv[j];
+            r_base = s_read[j - 1];
+        }
+        if (in_row) {
+            if (j == 1) {  // row start: column 0 is all zeros and carries no horizontal gap
+                val = (S)0;
+                up_prev = (S)0;
+                bgh = kNoGap;
+                gsh = 0;
             }
-            const int j = t - lane;
-            if (j >= 1 && j <= m) {
-                const S step_diag = up_prev + ((unsigned)r_base == a_base ? wm : wx);
-                S prev_gap = r_up + wo;
-                S bgv = r_bgv + we;
-                int gsv;
-                if (prev_gap > bgv) { bgv = prev_gap; gsv = 1; }
-                else gsv = r_gsv + 1;
-                prev_gap = val + wo;
-                bgh += we;
-                if (prev_gap > bgh) { bgh = prev_gap; gsh = 1; }
-                else gsh += 1;
-                S v;
-                int tr;
-                if (bgv > bgh) {
-                    if (bgv > step_diag) { v = bgv; tr = gsv; }
-                    else { v = step_diag; tr = 0; }
-                } else {
-                    if (bgh > step_diag) { v = bgh; tr = -gsh; }
-                    else { v = step_diag; tr = 0; }
-                }
-                val = v > kCutoff ? v : kCutoff;
-                up_prev = r_up;
-                out_val = val;
-                out_bgv = bgv;
-                out_gsv = gsv;
-                out_base = r_base;
-                if (row_ok) {
-                    bt_blk[(size_t)(t - 1) * 64] = (short)tr;
-                    if (j == m) { my_last = val; have_last = true; }
-                    if (i == n) s_last[j] = val;
-                }
-                if (lane == 63) {
-                    s_up[j] = val;
-                    s_bgv[j] = bgv;
-                    s_gsv[j] = gsv;
-                }
+            const S step_diag = up_prev + ((unsigned)r_base == a_base ? wm : wx);
+            S prev_gap = r_up + wo;
+            S bgv = r_bgv + we;
+            int gsv;
+            if (prev_gap > bgv) { bgv = prev_gap; gsv = 1; }
+            else gsv = r_gsv + 1;
+            prev_gap = val + wo;
+            bgh += we;
+            if (prev_gap > bgh) { bgh = prev_gap; gsh = 1; }
+            else gsh += 1;
+            S v;
+            int tr;
+            if (bgv > bgh) {
+                if (bgv > step_diag) { v = bgv; tr = gsv; }
+                else { v = step_diag; tr = 0; }
+            } else {
+                if (bgh > step_diag) { v = bgh; tr = -gsh; }
+                else { v = step_diag; tr = 0; }
+            }
+            val = v > kCutoff ? v : kCutoff;
+            up_prev = r_up;
+            out_val = val;
+            out_bgv = bgv;
+            out_gsv = gsv;
+            out_base = r_base;
+            if (row_ok) {
+                bt[((size_t)rb * T + (size_t)(j + lane - 1)) * 64 + lane] = (short)tr;
+                // last column: max score, the largest row among equals (rows come in ascending order)
+                if (j == m && val >= best_s) { best_s = val; best_i = i; }
+                if (i == n) s_last[j] = val;
+            }
+            if (lane == 63) {
+                s_up[j] = val;
+                s_bgv[j] = bgv;
+                s_gsv[j] = gsv;
             }
         }
-        // last column of this block: max score, the largest row among equals; ">=" against the
-        // running best (earlier blocks are earlier rows)
-        S bs = have_last ? my_last : SwLimits<S>::lowest();
-        int bi = have_last ? i : 0;
+        j += 1;
+        if (j > P) {  // on to this lane's row of the next block
+            j = 1;
+            rb += 1;
+            i += 64;
+            row_ok = i <= n;
+            a_base = row_ok ? a[i - 1] : 0x100u;
+        }
+    }
+    // first scan of the start cell: best of the last column over all rows, larger rows win ties,
+    // and only scores >= 0 (the scan starts from score 0 at row 0)
+    S col_best = best_s;
+    int col_best_i = best_i;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const S os = xor_s(bs, off);
-            const int oi = __shfl_xor(bi, off);
-            if (os > bs || (os == bs && oi > bi)) { bs = os; bi = oi; }
-        }
-        if (bi > 0 && bs >= col_best) { col_best = bs; col_best_i = bi; }
+    for (int off = 32; off > 0; off >>= 1) {
+        const S os = xor_s(col_best, off);
+        const int oi = __shfl_xor(col_best_i, off);
+        if (os > col_best || (os == col_best && oi > col_best_i)) { col_best = os; col_best_i = oi; }
     }
 
     // ---- start cell (calculateCigar, first part); every lane runs the same scalar walk ----
