@@ -4,9 +4,11 @@
 //
 // v_mfma_f32_16x16x32_bf16 wants, in lane l, eight consecutive k of one row (A) or one
 // column (B): A[row l&15][k = 8(l>>4) + j], B[k = 8(l>>4) + j][col l&15], j = 0..7.  A
-// workgroup (2 x 2 waves) owns a 128 x 128 tile of C and walks K in tiles of 64; each
-// operand tile lives in LDS in one of two images, chosen by which GEMM dimension is
-// unit-stride in memory:
+// workgroup owns a BT x BT tile of C (BT = 128: 2 x 2 waves of 64 x 64, two workgroups per
+// CU; BT = 256: 2 x 4 waves of 128 x 64, one workgroup per CU, half the operand bytes per
+// flop on the L2 -> LDS path, which is what bounds the 128 tile on large problems) and walks
+// K in tiles of 64; each operand tile lives in LDS in one of two images, chosen by which
+// GEMM dimension is unit-stride in memory:
 //   K-major image  [row][64 k], 128-byte rows.  The 16-byte chunk c (8 k) of row r sits at
 //                  128 r + 16 (c ^ ((r >> 1) & 7)).  Filled with 16-byte vectors along K
 //                  (or element by element when no vectors are legal); a fragment is one
@@ -14,8 +16,8 @@
 //                  together ({0-3, 12-15, 20-27}, ...: eight rows at chunk c and eight at
 //                  chunk c ^ 1) fall on sixteen different 16-byte slots of the 256-byte
 //                  bank row.
-//   outer image    [k][128 rows], 256-byte rows, chunk c (8 rows) of line k at
-//                  256 k + 16 (c ^ (((k & 3) << 2) | ((k >> 2) & 3))).  Filled with 16-byte
+//   outer image    [k][BT rows], 2 BT-byte lines, chunk c (8 rows) of line k at
+//                  2 BT k + 16 (c ^ (((k & 3) << 2) | ((k >> 2) & 3))).  Filled with 16-byte
 //                  vectors along the rows; a fragment is two ds_read_b64_tr_b16 (the
 //                  hardware transposes a block of 4 k x 16 rows per 16 lanes), conflict-free
 //                  because the two blocks a 32-lane half reads are 8 lines apart.
@@ -42,13 +44,15 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
-constexpr int kImageBytes = 128 * BK * 2;  // either image of a 128-row operand tile: 16 KiB
+constexpr int BK = 64;
+// BT: edge of the square C tile (128 or 256).  2 BT threads; either image of a BT-row operand
+// tile takes 128 BT bytes (16 or 32 KiB).
+template <int BT> constexpr int image_bytes() { return BT * BK * 2; }
 
 __device__ __forceinline__ int kmaj_off(int row, int chunk) { return 128 * row + 16 * (chunk ^ ((row >> 1) & 7)); }
-__device__ __forceinline__ int outer_off(int k, int chunk)
+template <int BT> __device__ __forceinline__ int outer_off(int k, int chunk)
 {
-    return 256 * k + 16 * (chunk ^ (((k & 3) << 2) | ((k >> 2) & 3)));
+    return 2 * BT * k + 16 * (chunk ^ (((k & 3) << 2) | ((k >> 2) & 3)));
 }
 
 __device__ __forceinline__ unsigned short f32_to_bf16(float f)
@@ -60,17 +64,17 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f)
 }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 
-// Stages one 128 x 64 operand tile.  tab_rows / tab_k are the operand's element-offset
+// Stages one BT x 64 operand tile with 2 BT threads.  tab_rows / tab_k are the operand's element-offset
 // tables (rows: M or N index, k: K index; the device k tables carry kKTablePad extra
 // entries, so k0 + 63 is always a valid index).  Rows past the operand's extent are
 // clamped (their products land in C elements that are never stored); k past K reads
 // as zero.
-template <int LAY> struct StagerBf16;
+template <int LAY, int BT> struct StagerBf16;
 
 // LDS-DMA (global_load_lds_dwordx4): lane l of a wave instruction writes 16 bytes at the wave's
-// LDS base + 16 l, so a thread must fetch the chunk whose image slot is 16 t + 4096 i: the
-// swizzle is applied to the SOURCE chunk (which is the same for all four of a thread's
-// passes, because the XOR term repeats every 16 rows / 16 lines).
+// LDS base + 16 l, so a thread must fetch the chunk whose image slot is 16 t + 32 BT i (pass i
+// of four): the swizzle is applied to the SOURCE chunk (which is the same for all four of a
+// thread's passes, because the XOR term repeats every 16 rows / 16 lines).
 __device__ __forceinline__ void dma16(const void *src, unsigned char *lds_wave_base)
 {
     typedef __attribute__((address_space(1))) const void *gptr_t;
@@ -78,7 +82,8 @@ __device__ __forceinline__ void dma16(const void *src, unsigned char *lds_wave_b
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <> struct StagerBf16<0 /* unit stride along K */> {
+template <int BT> struct StagerBf16<0 /* unit stride along K */, BT> {
+    static constexpr int RPP = BT / 4;  // rows per pass
     static constexpr bool OUTER = false;
     static constexpr bool DIRECT = true;
     int64_t fix_off[4];
@@ -90,7 +95,7 @@ template <> struct StagerBf16<0 /* unit stride along K */> {
         row0 = t >> 3;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int64_t r = r0 + row0 + 32 * i;
+            const int64_t r = r0 + row0 + RPP * i;
             fix_off[i] = tab_rows[r < R ? r : R - 1];
         }
     }
@@ -109,7 +114,7 @@ template <> struct StagerBf16<0 /* unit stride along K */> {
     __device__ __forceinline__ void direct(const unsigned short *__restrict__ base, unsigned char *img, int wave)
     {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(base + fix_off[i] + koff, img + 4096 * i + 1024 * wave);
+        for (int i = 0; i < 4; ++i) dma16(base + fix_off[i] + koff, img + 32 * BT * i + 1024 * wave);
     }
     __device__ __forceinline__ void commit(unsigned char *lds, int64_t k0, int64_t K)
     {
@@ -118,21 +123,22 @@ template <> struct StagerBf16<0 /* unit stride along K */> {
         for (int i = 0; i < 4; ++i) {
             u4_t v = regs[i];
             if (!live) v = u4_t{0, 0, 0, 0};
-            *reinterpret_cast<u4_t *>(lds + kmaj_off(row0 + 32 * i, chunk)) = v;
+            *reinterpret_cast<u4_t *>(lds + kmaj_off(row0 + RPP * i, chunk)) = v;
         }
     }
 };
 
-template <> struct StagerBf16<kLayOuterVec /* unit stride along the rows */> {
+template <int BT> struct StagerBf16<kLayOuterVec /* unit stride along the rows */, BT> {
     static constexpr bool OUTER = true;
     static constexpr bool DIRECT = true;
+    static constexpr int CPL = BT / 8;  // 16-byte chunks per line
     int64_t fix_off;
     u4_t regs[4];
     int chunk, line0;
     __device__ __forceinline__ void init(const int64_t *__restrict__ tab_rows, int64_t r0, int64_t R, int t)
     {
-        line0 = t >> 4;
-        chunk = (t & 15) ^ (((line0 & 3) << 2) | ((line0 >> 2) & 3));  // lands in slot t & 15 of its line
+        line0 = t / CPL;  // 0..15
+        chunk = (t % CPL) ^ (((line0 & 3) << 2) | ((line0 >> 2) & 3));  // lands in slot t % CPL of its line
         const int64_t r = r0 + 8 * chunk;
         fix_off = tab_rows[r < R ? r : R - 8];  // R is a multiple of 8 whenever this layout is chosen
     }
@@ -152,7 +158,7 @@ template <> struct StagerBf16<kLayOuterVec /* unit stride along the rows */> {
     __device__ __forceinline__ void direct(const unsigned short *__restrict__ base, unsigned char *img, int wave)
     {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(base + fix_off + koff[i], img + 4096 * i + 1024 * wave);
+        for (int i = 0; i < 4; ++i) dma16(base + fix_off + koff[i], img + 32 * BT * i + 1024 * wave);
     }
     __device__ __forceinline__ void commit(unsigned char *lds, int64_t k0, int64_t K)
     {
@@ -160,16 +166,17 @@ template <> struct StagerBf16<kLayOuterVec /* unit stride along the rows */> {
         for (int i = 0; i < 4; ++i) {
             u4_t v = regs[i];
             if (k0 + line0 + 16 * i >= K) v = u4_t{0, 0, 0, 0};
-            *reinterpret_cast<u4_t *>(lds + outer_off(line0 + 16 * i, chunk)) = v;
+            *reinterpret_cast<u4_t *>(lds + outer_off<BT>(line0 + 16 * i, chunk)) = v;
         }
     }
 };
 
-template <> struct StagerBf16<kLayScalar /* element loads, any strides */> {
+template <int BT> struct StagerBf16<kLayScalar /* element loads, any strides */, BT> {
     // The fallback when no 16-byte vectors are legal (odd extents, odd strides, unaligned
-    // base).  A thread owns 8 rows x 4 k of the tile; sixteen neighbouring lanes run along
-    // whichever of the two dimensions is contiguous in memory.  Element pairs share a
-    // register while the tile waits for the MFMAs of the previous one.
+    // base); 128 tile only.  A thread owns 8 rows x 4 k of the tile; sixteen neighbouring
+    // lanes run along whichever of the two dimensions is contiguous in memory.  Element pairs
+    // share a register while the tile waits for the MFMAs of the previous one.
+    static_assert(BT == 128, "element loads are staged for the 128 tile only");
     static constexpr bool OUTER = false;
     static constexpr bool DIRECT = false;
     int64_t fix_off[8];
@@ -219,32 +226,39 @@ template <> struct StagerBf16<kLayScalar /* element loads, any strides */> {
 };
 
 // MFMA operand of the 16 rows (columns) starting at r16 for k-step ks (32 k) of a tile image
-template <bool OUTER> __device__ __forceinline__ bf8_t fragment(const unsigned char *img, int r16, int ks, int lane)
+template <bool OUTER, int BT> __device__ __forceinline__ bf8_t fragment(const unsigned char *img, int r16, int ks, int lane)
 {
     if constexpr (!OUTER) {
         const int row = r16 + (lane & 15);
         return *reinterpret_cast<const bf8_t *>(img + kmaj_off(row, 4 * ks + (lane >> 4)));
     } else {
     // lane 4q+p of a 16-lane group names line q, rows 4p..4p+3 of the block; it receives the
-    // four lines of row (lane & 15)
+    // four lines of row (lane & 15).  Lines k = 32 ks + 8 g + q and k + 4; their XOR terms are
+    // 2 Y and 2 Y + 1 with Y = 2 q + (g & 1), so chunk (r16 / 8 + (p >> 1)) of the two lines sits
+    // at 32 ((r16 / 16) ^ Y) + 16 (p >> 1) and at the same place with bit 4 flipped: one XOR with
+    // the (wave-uniform) row block per fragment, everything else is per-lane constant or immediate.
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int k = 32 * ks + 8 * g + q;
-    const int ch = (r16 >> 3) + (p >> 1);
+    const int lane_off = 2 * BT * (8 * g + q) + 16 * (p >> 1) + 8 * (p & 1);
+    const int y32 = 32 * (2 * q + (g & 1));
+    const int off = lane_off + ((2 * r16) ^ y32);
     typedef s4_t __attribute__((address_space(3))) * lds_s4_ptr;
     const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (lds_s4_ptr)(const_cast<unsigned char *>(img) + outer_off(k, ch) + 8 * (p & 1)));
+        (lds_s4_ptr)(const_cast<unsigned char *>(img) + off + 64 * BT * ks));
     const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (lds_s4_ptr)(const_cast<unsigned char *>(img) + outer_off(k + 4, ch) + 8 * (p & 1)));
+        (lds_s4_ptr)(const_cast<unsigned char *>(img) + (off ^ 16) + 64 * BT * ks + 8 * BT));
     const s8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf8_t, both);
     }
 }
 
-template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_kernel(const GemmParams p)
+template <int LA, int LB, int BT>
+__global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(const GemmParams p)
 {
-    typedef StagerBf16<LA> SA;
-    typedef StagerBf16<LB> SB;
-    constexpr int TM = 4, TN = 4;  // 16 x 16 accumulators per wave: a 64 x 64 block of C
+    typedef StagerBf16<LA, BT> SA;
+    typedef StagerBf16<LB, BT> SB;
+    constexpr int BM = BT, BN = BT, kImageBytes = image_bytes<BT>();
+    // 16 x 16 accumulators per wave: a 64 x 64 (BT = 128) or 128 x 64 (BT = 256) block of C
+    constexpr int TM = BT / 32, TN = 4, WAVES_N = BT / 64;
 
     // [buffer][A image | B image]
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * kImageBytes];
@@ -252,7 +266,7 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave / WAVES_N) * (16 * TM), wn0 = (wave % WAVES_N) * 64;
 
     // Block -> item.  Blocks b and b+8 share an XCD (and its L2), so every XCD gets a contiguous
     // run of tile ids, walked in groups of `group` tile rows to share A and B panels.  The
@@ -307,12 +321,18 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
         typedef std::remove_reference_t<decltype(st)> S;
         return S::DIRECT && k0 + BK <= p.K;
     };
+    // The 256 tile has no registers to hold a tile across the MFMAs: its one register-staged
+    // tile (the K tail) is loaded and committed after them, unoverlapped.
+    constexpr bool kLateIssue = BT == 256;
     auto stage_begin = [&](auto &st, const unsigned short *base, const int64_t *tab_k, int64_t k0, unsigned char *img) {
         if (is_direct(st, k0)) st.direct(base, img, wave);
-        else st.issue(base, tab_k, k0, p.K);
+        else if (!kLateIssue) st.issue(base, tab_k, k0, p.K);
     };
-    auto stage_end = [&](auto &st, int64_t k0, unsigned char *img) {
-        if (!is_direct(st, k0)) st.commit(img, k0, p.K);
+    auto stage_end = [&](auto &st, const unsigned short *base, const int64_t *tab_k, int64_t k0, unsigned char *img) {
+        if (!is_direct(st, k0)) {
+            if (kLateIssue) st.issue(base, tab_k, k0, p.K);
+            st.commit(img, k0, p.K);
+        }
     };
     // k offsets of a DMA tile are fetched one tile ahead (the k tables are padded past K, but
     // only by one tile)
@@ -329,8 +349,8 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
         stage_begin(sa, A, p.k_a, k_first, smem);
         stage_begin(sb, B, p.k_b, k_first, smem + kImageBytes);
         prefetch(kt_first + 1);
-        stage_end(sa, k_first, smem);
-        stage_end(sb, k_first, smem + kImageBytes);
+        stage_end(sa, A, p.k_a, k_first, smem);
+        stage_end(sb, B, p.k_b, k_first, smem + kImageBytes);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA counts as an outstanding load
     __syncthreads();
@@ -352,13 +372,45 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
         // half of the reads lands while the first sixteen MFMAs run; the order is pinned, the
         // compiler only adds the counted waits.
         static_assert(BK == 64, "two k-steps per tile");
+        if constexpr (BT == 256) {
+            // 128 accumulator registers leave no room for both k-steps' fragments (24 x 4
+            // registers): the A fragments are a rolling set, row i of the second k-step is
+            // requested right behind the four MFMAs that consumed row i of the first.
+            bf8_t fa[TM], fb[2][TN];
+            // the fragment addresses are rebuilt from the lane id in every tile (a few VALU
+            // instructions) instead of living in two dozen registers across the loop
+            int lane_it = lane;
+            asm volatile("" : "+v"(lane_it));
+            fa[0] = fragment<SA::OUTER, BT>(ia, wm0, 0, lane_it);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = fragment<SB::OUTER, BT>(ib, wn0 + 16 * j, 0, lane_it);
+#pragma unroll
+            for (int i = 1; i < TM; ++i) fa[i] = fragment<SA::OUTER, BT>(ia, wm0 + 16 * i, 0, lane_it);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[1][j] = fragment<SB::OUTER, BT>(ib, wn0 + 16 * j, 1, lane_it);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[0][j], acc[i][j], 0, 0, 0);
+                fa[i] = fragment<SA::OUTER, BT>(ia, wm0 + 16 * i, 1, lane_it);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
         bf8_t fa[2][TM], fb[2][TN];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[ks][i] = fragment<SA::OUTER>(ia, wm0 + 16 * i, ks, lane);
+            for (int i = 0; i < TM; ++i) fa[ks][i] = fragment<SA::OUTER, BT>(ia, wm0 + 16 * i, ks, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[ks][j] = fragment<SB::OUTER>(ib, wn0 + 16 * j, ks, lane);
+            for (int j = 0; j < TN; ++j) fb[ks][j] = fragment<SB::OUTER, BT>(ib, wn0 + 16 * j, ks, lane);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -370,9 +422,10 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         if (more) {
-            stage_end(sa, k_next, na);
-            stage_end(sb, k_next, na + kImageBytes);
+            stage_end(sa, A, p.k_a, k_next, na);
+            stage_end(sb, B, p.k_b, k_next, na + kImageBytes);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -447,8 +500,9 @@ template <int LA, int LB> __global__ void __launch_bounds__(NT, 2) gemm_bf16_ker
 
 // Sums the K chunks of the split tiles in chunk order and writes C = alpha * sum + beta * C in bf16.
 // One workgroup per (tile, 16 rows); a thread owns two neighbouring columns.
-__global__ void __launch_bounds__(256) splitk_fixup_bf16_kernel(const GemmParams p)
+template <int BT> __global__ void __launch_bounds__(256) splitk_fixup_bf16_kernel(const GemmParams p)
 {
+    constexpr int BM = BT, BN = BT;
     constexpr int ROWS = 16, VPR = BN / 2, RPP = 256 / VPR;  // column pairs per row, rows per pass
     const int tile_rel = blockIdx.x / (BM / ROWS);
     const int rblk = blockIdx.x % (BM / ROWS);
@@ -489,8 +543,9 @@ __global__ void __launch_bounds__(256) splitk_fixup_bf16_kernel(const GemmParams
     }
 }
 
-// workgroup slots of the current device (two workgroups per CU: 64 KB of LDS each)
-int bf16_slots()
+// workgroup slots of the current device: two workgroups per CU with the 128 tile (64 KB of LDS
+// each), one with the 256 tile (128 KB)
+template <int BT> int bf16_slots()
 {
     static int cache[64] = {0};
     int dev = 0;
@@ -498,7 +553,7 @@ int bf16_slots()
     if (cache[dev] == 0) {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_bf16_kernel<0, 0>, NT, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_bf16_kernel<0, 0, BT>, 2 * BT, 0) != hipSuccess) return 0;
         cache[dev] = cus * per_cu > 0 ? cus * per_cu : -1;
     }
     return cache[dev] > 0 ? cache[dev] : 0;
@@ -506,7 +561,13 @@ int bf16_slots()
 
 constexpr int kMinChunkTilesBf16 = 16;  // K-tiles (of 64) per chunk at least: shorter chunks cost more in the second launch than they save
 
-template <int LA, int LB> hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
+// The 256 tile exists for the 16-byte-vector layouts only; a request for it with an operand
+// that has to be read element by element (the planner never makes one; an unaligned base can
+// demote a layout at execution time) runs on the 128 tile.
+int tile_edge(int la, int lb, int bm) { return bm == 256 && la != kLayScalar && lb != kLayScalar ? 256 : 128; }
+
+template <int LA, int LB, int BT>
+hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     GemmParams q = p;
     q.nbm = sch.nbm;
@@ -516,10 +577,11 @@ template <int LA, int LB> hipError_t launch_one(const GemmParams &p, const GemmS
     q.ws = ws;
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_bf16_kernel<LA, LB>), dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1),
-                       dim3(NT), 0, stream, q);
+    if (sch.nbm != (int)((p.M + BT - 1) / BT) || sch.nbn != (int)((p.N + BT - 1) / BT)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_bf16_kernel<LA, LB, BT>), dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1),
+                       dim3(2 * BT), 0, stream, q);
     if (sch.tail_tiles > 0)
-        hipLaunchKernelGGL(splitk_fixup_bf16_kernel, dim3((unsigned)(sch.tail_tiles * (BM / 16))), dim3(256), 0, stream, q);
+        hipLaunchKernelGGL(splitk_fixup_bf16_kernel<BT>, dim3((unsigned)(sch.tail_tiles * (BT / 16))), dim3(256), 0, stream, q);
     return hipGetLastError();
 }
 
@@ -527,14 +589,14 @@ template <int LA, int LB> hipError_t launch_one(const GemmParams &p, const GemmS
 
 // Same policy as the f64/f32 kernel: tiles = q * slots + tail; the q full rounds run whole, each
 // tail tile is cut along K into floor(slots / tail) chunks.  Problems with fewer tiles than
-// slots are split entirely, which is what keeps medium-sized contractions on the whole chip
-// (this kernel has one tile shape).
-hipError_t schedule_gemm_bf16(const GemmParams &p, GemmSchedule *out)
+// slots are split entirely, which is what keeps medium-sized contractions on the whole chip.
+hipError_t schedule_gemm_bf16(int la, int lb, int bm, const GemmParams &p, GemmSchedule *out)
 {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
+    const int bt = tile_edge(la, lb, bm);
     GemmSchedule s;
-    s.nbm = (int)((p.M + BM - 1) / BM);
-    s.nbn = (int)((p.N + BN - 1) / BN);
+    s.nbm = (int)((p.M + bt - 1) / bt);
+    s.nbn = (int)((p.N + bt - 1) / bt);
     const int64_t tiles = (int64_t)s.nbm * s.nbn;
     if (tiles > 0x7FFFFFFF) return hipErrorInvalidValue;
     s.dp_tiles = (int)tiles;
@@ -542,7 +604,7 @@ hipError_t schedule_gemm_bf16(const GemmParams &p, GemmSchedule *out)
     s.tail_tiles = 0;
     s.ws_bytes = 0;
     static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
-    const int slots = bf16_slots();
+    const int slots = bt == 256 ? bf16_slots<256>() : bf16_slots<128>();
     const int nk = (int)((p.K + BK - 1) / BK);
     if (!no_split && slots > 0 && p.batch == 1) {
         const int tail = (int)(tiles % slots);
@@ -553,7 +615,7 @@ hipError_t schedule_gemm_bf16(const GemmParams &p, GemmSchedule *out)
                 s.tail_tiles = tail;
                 s.dp_tiles = (int)tiles - tail;
                 s.split = f;
-                s.ws_bytes = (size_t)tail * f * BM * BN * sizeof(float);
+                s.ws_bytes = (size_t)tail * f * bt * bt * sizeof(float);
             }
         }
     }
@@ -561,12 +623,21 @@ hipError_t schedule_gemm_bf16(const GemmParams &p, GemmSchedule *out)
     return hipSuccess;
 }
 
-hipError_t launch_gemm_bf16(int la, int lb, const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
+hipError_t launch_gemm_bf16(int la, int lb, int bm, const GemmParams &p, const GemmSchedule &sch, void *ws,
+                            hipStream_t stream)
 {
     if (la < 0 || la > 2 || lb < 0 || lb > 2) return hipErrorInvalidValue;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
+    if (tile_edge(la, lb, bm) == 256) {
+        switch (la * 2 + lb) {
+        case 0: return launch_one<0, 0, 256>(p, sch, ws, stream);
+        case 1: return launch_one<0, 1, 256>(p, sch, ws, stream);
+        case 2: return launch_one<1, 0, 256>(p, sch, ws, stream);
+        default: return launch_one<1, 1, 256>(p, sch, ws, stream);
+        }
+    }
 #define CTC_CASE(A_, B_) \
-    case A_ * 3 + B_: return launch_one<A_, B_>(p, sch, ws, stream);
+    case A_ * 3 + B_: return launch_one<A_, B_, 128>(p, sch, ws, stream);
     switch (la * 3 + lb) {
         CTC_CASE(0, 0) CTC_CASE(0, 1) CTC_CASE(0, 2) CTC_CASE(1, 0) CTC_CASE(1, 1) CTC_CASE(1, 2)
         CTC_CASE(2, 0) CTC_CASE(2, 1) CTC_CASE(2, 2)

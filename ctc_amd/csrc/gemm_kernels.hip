@@ -598,14 +598,14 @@ hipError_t dispatch(int dtype, int la, int lb, int bm, int bn, const GemmParams 
 
 hipError_t schedule_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p, GemmSchedule *out)
 {
-    if (dtype == 2) return schedule_gemm_bf16(p, out);
+    if (dtype == 2) return schedule_gemm_bf16(layout_a, layout_b, bm, p, out);
     return dispatch(dtype, layout_a, layout_b, bm, bn, p, out, nullptr, nullptr, nullptr);
 }
 
 hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
                        const GemmSchedule &schedule, void *workspace, hipStream_t stream)
 {
-    if (dtype == 2) return launch_gemm_bf16(layout_a, layout_b, p, schedule, workspace, stream);
+    if (dtype == 2) return launch_gemm_bf16(layout_a, layout_b, bm, p, schedule, workspace, stream);
     return dispatch(dtype, layout_a, layout_b, bm, bn, p, nullptr, &schedule, workspace, stream);
 }
 

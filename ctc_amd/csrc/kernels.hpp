@@ -47,10 +47,11 @@ hipError_t schedule_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, 
 hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
                        const GemmSchedule &schedule, void *workspace, hipStream_t stream);
 
-// bf16 operands and result, f32 accumulation (gemm_bf16_kernels.hip): one 128 x 128 x 64 tile shape;
+// bf16 operands and result, f32 accumulation (gemm_bf16_kernels.hip): square tiles, bm = 128 or 256
+// (256 only with 16-byte-vector layouts on both operands, otherwise 128 is used), K-tile 64;
 // reached through schedule_gemm / launch_gemm with dtype 2.
-hipError_t schedule_gemm_bf16(const GemmParams &p, GemmSchedule *out);
-hipError_t launch_gemm_bf16(int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
+hipError_t schedule_gemm_bf16(int layout_a, int layout_b, int bm, const GemmParams &p, GemmSchedule *out);
+hipError_t launch_gemm_bf16(int layout_a, int layout_b, int bm, const GemmParams &p, const GemmSchedule &schedule,
                             void *workspace, hipStream_t stream);
 
 // Skinny contraction C(m,n) = sum_k A(m,k) B(k,n) for M <= 16: streams B once and C once.

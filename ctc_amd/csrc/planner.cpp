@@ -107,6 +107,8 @@ int vector_width(const Plan &p, const std::vector<int> &operand_modes,
     return vmax;
 }
 
+constexpr int64_t kBf16BigTileMinBlocks = 192;
+
 void choose_tile(Plan &p)
 {
     Tile t;
@@ -126,11 +128,20 @@ void choose_tile(Plan &p)
         if (atoi(force) == 128) { t.bm = 128; t.bn = 128; }
     }
     t.bk = 16;
-    if (p.dtype == kBF16) {
-        // the bf16 kernel has one tile shape
-        t.bm = 128; t.bn = 128; t.bk = 64;
-    }
     t.threads = 256;
+    if (p.dtype == kBF16) {
+        // Square tiles, K-tile 64.  The 256 tile moves half the operand bytes per flop from L2
+        // to LDS; it needs 16-byte-vector layouts on both operands and enough tiles for the
+        // 256 CUs (one workgroup per CU).
+        t.bm = 128; t.bn = 128; t.bk = 64;
+        const bool vectors = p.layout_a != kLayoutScalar && p.layout_b != kLayoutScalar;
+        bool big = vectors && blocks(256, 256) >= kBf16BigTileMinBlocks;
+        if (const char *force = getenv("CTC_TC_FORCE_TILE")) {
+            if (atoi(force) == 128) big = false;
+            if (atoi(force) == 256) big = vectors;
+        }
+        if (big) { t.bm = 256; t.bn = 256; t.threads = 512; }
+    }
     t.group = 8;
     p.tile = t;
 }

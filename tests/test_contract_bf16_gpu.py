@@ -85,6 +85,81 @@ def test_bf16_against_oracle(cuda, oracle, name, spec, ext, layouts):
     _check(oracle, _to_host(dC), oracle.contract(spec, ext, A, B, dtype=BF16))
 
 
+# The 256 x 256 tile (512 threads, one workgroup per CU) is chosen on its own once a problem has
+# enough tiles of that size for the chip; CTC_TC_FORCE_TILE=256 selects it for small problems.
+BIG_TILE_CASES = [
+    ("nn_ragged", "ak,kb->ab", dict(a=520, b=392, k=200), ("k_vec", "outer_vec")),
+    ("nt_ragged", "ak,bk->ab", dict(a=264, b=648, k=72), ("k_vec", "k_vec")),
+    ("tn_ragged", "ka,kb->ab", dict(a=392, b=520, k=136), ("outer_vec", "outer_vec")),
+    ("tt_one_tile", "ka,bk->ab", dict(a=256, b=256, k=64), ("outer_vec", "k_vec")),
+    ("smaller_than_a_tile", "ak,kb->ab", dict(a=40, b=72, k=24), ("k_vec", "outer_vec")),
+    ("k_tail_shorter_than_a_tile", "ak,kb->ab", dict(a=264, b=264, k=104), None),
+    ("splitk", "ak,kb->ab", dict(a=768, b=520, k=4096), ("k_vec", "outer_vec")),
+    ("splitk_nt_k_tail", "ak,bk->ab", dict(a=300, b=264, k=3064), ("k_vec", "k_vec")),
+    ("ccsd_24", "aeim,ebmj->abij", dict(a=24, b=24, i=24, j=24, e=16, m=24), None),
+    ("batched", "zak,zkb->zab", dict(z=3, a=264, b=328, k=72), None),
+]
+
+
+@pytest.mark.parametrize("name,spec,ext,layouts", BIG_TILE_CASES, ids=[c[0] for c in BIG_TILE_CASES])
+def test_bf16_big_tile_forced(cuda, oracle, monkeypatch, name, spec, ext, layouts):
+    monkeypatch.setenv("CTC_TC_FORCE_TILE", "256")
+    na, nb, nc = _sizes(spec, ext)
+    A = oracle.fill(na, 0xC7C0A, BF16)
+    B = oracle.fill(nb, 0xC7C0B, BF16)
+    plan = ctc_amd.Plan(spec, ext, "bf16")
+    s = plan.summary()
+    assert s["kernel"] == "mfma_gemm" and tuple(s["tile"]) == (256, 256, 64), s
+    if layouts is not None:
+        assert (s["layout_a"], s["layout_b"]) == layouts
+    C0 = oracle.fill(nc, 99, BF16)
+    dC = _to_dev(C0.copy(), cuda)
+    plan.execute(_to_dev(A, cuda), _to_dev(B, cuda), dC, alpha=2.0, beta=0.5)
+    _check(oracle, _to_host(dC), oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=2.0, beta=0.5, dtype=BF16))
+
+
+def test_bf16_big_tile_forced_on_scalar_layout_stays_small(monkeypatch):
+    monkeypatch.setenv("CTC_TC_FORCE_TILE", "256")
+    s = ctc_amd.Plan("ak,kb->ab", dict(a=67, b=45, k=77), "bf16").summary()
+    assert tuple(s["tile"]) == (128, 128, 64)
+
+
+def test_bf16_big_tile_chosen_and_exact_on_small_integers(cuda):
+    """16 x 12 tiles of 256: the planner takes the big tile by itself.  Integer operands make the
+    result exact, so it must equal torch's f64 product bit for bit, in all four operand layouts."""
+    m, n, k = 4096, 3072, 96
+    g = torch.Generator().manual_seed(11)
+    A = torch.randint(-2, 3, (m, k), generator=g).to(torch.float32)
+    B = torch.randint(-1, 2, (k, n), generator=g).to(torch.float32)
+    want = A.double() @ B.double()
+    assert want.abs().max() < 256
+    for spec, a, b in (("ak,kb->ab", A, B), ("ka,kb->ab", A.t().contiguous(), B),
+                       ("ak,bk->ab", A, B.t().contiguous()), ("ka,bk->ab", A.t().contiguous(), B.t().contiguous())):
+        plan = ctc_amd.Plan(spec, dict(a=m, b=n, k=k), "bf16")
+        assert tuple(plan.summary()["tile"]) == (256, 256, 64), spec
+        dA = a.to(cuda).to(torch.bfloat16).reshape(-1)
+        dB = b.to(cuda).to(torch.bfloat16).reshape(-1)
+        dC = torch.full((m * n,), float("nan"), dtype=torch.bfloat16, device=cuda)
+        plan.execute(dA, dB, dC)
+        assert torch.equal(dC.double().cpu().reshape(m, n), want), spec
+
+
+def test_bf16_big_tile_unaligned_base_runs_on_small_tile(cuda, oracle, monkeypatch):
+    """A plan made for the big tile whose operand base turns out unaligned at execution time is
+    demoted to element loads, which only the 128 tile has."""
+    monkeypatch.setenv("CTC_TC_FORCE_TILE", "256")
+    spec, ext = "ak,kb->ab", dict(a=264, b=136, k=64)
+    na, nb, nc = _sizes(spec, ext)
+    A = oracle.fill(na + 1, 5, BF16)
+    B = oracle.fill(nb, 6, BF16)
+    want = oracle.contract(spec, ext, A[1:].copy(), B, dtype=BF16)
+    plan = ctc_amd.Plan(spec, ext, "bf16")
+    assert tuple(plan.summary()["tile"]) == (256, 256, 64)
+    dC = torch.full((nc,), float("nan"), dtype=torch.bfloat16, device=cuda)
+    plan.execute(_to_dev(A, cuda)[1:], _to_dev(B, cuda), dC)
+    _check(oracle, _to_host(dC), want)
+
+
 def test_bf16_golden_vector(cuda, oracle, golden):
     """The committed numpy.einsum samples of the bf16 case."""
     n = 0
