@@ -114,6 +114,8 @@ std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, P
             used[i] = 1;
             vol *= ext[i];
         }
+        // fastest first in output order: consecutive o values (one workgroup walks a few) extend the
+        // contiguous runs of the stores; ordering them by the input instead measured 5 % slower
         for (int p = r - 1; p >= 0; --p)
             if (!used[q[p]]) om.push_back(q[p]);
     }
