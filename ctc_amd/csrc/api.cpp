@@ -265,6 +265,8 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     g.group = p.tile.group;
     // 16-byte stores of C need an aligned base as well
     g.c_vec = (p.vec_c > 1 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) ? p.vec_c : 1;
+    // a result larger than the 256 MiB Infinity Cache cannot stay resident for a consumer anyway
+    g.c_stream = (double)p.M * (double)p.N * (double)p.batch * (double)ctc::dtype_size(p.dtype) > 256.0 * 1048576.0;
 
     // vector loads need 16-byte aligned bases; otherwise fall back to element loads
     int la = p.layout_a, lb = p.layout_b;

@@ -349,8 +349,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     };
     // Same with 16-byte stores (see Traits::cvec): half (f64) or a quarter (f32) of the store
     // instructions, which is what bounds the epilogue of contractions with a short K.
-    auto store_rows_vec = [&](auto with_beta_t) {
+    // STREAM: C does not fit the Infinity Cache, so its lines are stored with the non-temporal hint and
+    // leave the caches to the operand panels (config-4 contraction with |C| = 32.8 GB: 41.4 -> 47.7 TFLOP/s).
+    auto store_rows_vec = [&](auto with_beta_t, auto stream_t) {
         constexpr bool WITH_BETA = decltype(with_beta_t)::value;
+        constexpr bool STREAM = decltype(stream_t)::value;
         typedef typename Tr::vec_t vec_t;
         int64_t cvoff[TN];
 #pragma unroll
@@ -370,15 +373,17 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
 #endif
                         vec_t *dst = reinterpret_cast<vec_t *>(C + rvoff + cvoff[j]);
                         if (WITH_BETA) v += *dst * beta;
-                        *dst = v;
+                        if (STREAM) __builtin_nontemporal_store(v, dst);
+                        else *dst = v;
                     }
                 }
             }
         }
     };
     if (p.c_vec > 1) {
-        if (beta == (T)0) store_rows_vec(std::false_type());
-        else store_rows_vec(std::true_type());
+        if (beta != (T)0) store_rows_vec(std::true_type(), std::false_type());
+        else if (p.c_stream) store_rows_vec(std::false_type(), std::true_type());
+        else store_rows_vec(std::false_type(), std::false_type());
     } else {
         if (beta == (T)0) store_rows(std::false_type());
         else store_rows(std::true_type());

@@ -31,6 +31,7 @@ struct GemmParams {
     int dp_tiles = 0, split = 1;
     void *ws = nullptr;
     int c_vec = 1;  // > 1: C may be stored in 16-byte vectors of that many elements along N
+    int c_stream = 0;  // 1: C is larger than the Infinity Cache: store it with the non-temporal hint
 };
 
 struct GemmSchedule {
