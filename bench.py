@@ -55,7 +55,7 @@ def cpu_baseline(extent, threads):
 def measured_traffic(extent, kernel_summary):
     """HBM-side bytes per launch from the committed counter passes (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE, one pass each, tools/pmc_traffic.sh); None when they do not cover this run."""
-    path = os.path.join(ROOT, "profiles", "r01b_bench_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01c_bench_traffic.json")
     if extent != 96 or not os.path.exists(path):
         return None
     with open(path) as f:
@@ -238,7 +238,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
                 "traffic": measured_traffic(n, s) if world == 1 else None,
-                "traffic_unit": "bytes per launch at the L2's memory side (separate counter passes, profiles/r01b_bench_traffic.json)",
+                "traffic_unit": "bytes per launch at the L2's memory side (separate counter passes, profiles/r01c_bench_traffic.json)",
                 "algorithmic_bytes_per_launch": 3 * 8 * n ** 4,
                 "kernel": "gemm_kernel<double>",
                 "kernel_ms": round(kernel_ms, 4),

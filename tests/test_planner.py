@@ -88,6 +88,24 @@ def test_execution_view_headline_contraction():
     assert plan.flops == 2 * n ** 6
 
 
+def test_bf16_tile_choice(monkeypatch):
+    """bf16: 128 x 128 x 64 by default, 256 x 256 x 64 (512 threads) once the problem has 192 such
+    tiles and both operands can be read in 16-byte vectors; CTC_TC_FORCE_TILE overrides the count."""
+    small = ctc_amd.Plan("ak,kb->ab", dict(a=2048, b=2048, k=512), "bf16").summary()
+    assert tuple(small["tile"]) == (128, 128, 64)
+    big = ctc_amd.Plan("ak,kb->ab", dict(a=4096, b=3072, k=512), "bf16").summary()
+    assert tuple(big["tile"]) == (256, 256, 64)
+    odd = ctc_amd.Plan("ak,kb->ab", dict(a=4099, b=3073, k=511), "bf16").summary()  # element loads
+    assert (odd["layout_a"], odd["layout_b"]) == ("scalar", "scalar") and tuple(odd["tile"]) == (128, 128, 64)
+    monkeypatch.setenv("CTC_TC_FORCE_TILE", "128")
+    assert tuple(ctc_amd.Plan("ak,kb->ab", dict(a=4096, b=3072, k=512), "bf16").summary()["tile"]) == (128, 128, 64)
+    monkeypatch.setenv("CTC_TC_FORCE_TILE", "256")
+    assert tuple(ctc_amd.Plan("ak,kb->ab", dict(a=512, b=512, k=64), "bf16").summary()["tile"]) == (256, 256, 64)
+    # f64 plans are not touched by the bf16 rule
+    monkeypatch.delenv("CTC_TC_FORCE_TILE")
+    assert tuple(ctc_amd.Plan("ak,kb->ab", dict(a=4096, b=3072, k=512), "f64").summary()["tile"]) == (128, 128, 16)
+
+
 def test_swap_puts_c_unit_stride_mode_in_n():
     # C's fastest mode 'a' belongs to A: the planner exchanges the operand roles
     s = ctc_amd.Plan("ka,kb->ba", dict(a=20, b=12, k=18)).summary()

@@ -2,7 +2,7 @@
 rocpd sqlite output) into profiles/<name>: HBM-side bytes per launch of the headline contraction,
 with the gfx950 read calibration taken from the copy kernel of known size in the same run.
 
-  python tools/traffic_summary.py gpurun_out/traffic_FETCH_SIZE gpurun_out/traffic_WRITE_SIZE profiles/r01b_bench_traffic.json [extent]
+  python tools/traffic_summary.py gpurun_out/traffic_FETCH_SIZE gpurun_out/traffic_WRITE_SIZE profiles/r01c_bench_traffic.json [extent]
 """
 import glob
 import json
