@@ -9,6 +9,8 @@
 //                [--gen-a SEED --gen-b SEED]   synthetic inputs instead of files
 //                [--describe]                  print the plan and exit (needs no GPU)
 //                [--shard MODE:RANK/NRANKS]    compute one slab only
+//                [--ngpu N [--shard-on MODE]]  whole contraction on N GPUs of this node: one host thread
+//                                              per GPU, equal slabs of a free mode, no exchange
 //                [--time ITERS]                print device ms per contraction
 //   ctc_contract --permute abcd=dcba --extents a=..,b=.. --dtype f32 --a IN.bin --out OUT.bin
 //                                              mode permutation of one tensor (input modes = output modes)
@@ -23,6 +25,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ctc_tc.h"
@@ -78,7 +81,7 @@ int main(int argc, char **argv)
         if (a == "--help" || a == "-h") {
             printf("usage: ctc_contract --spec S --extents a=..,b=.. [--dtype f64|f32] --a FILE --b FILE --out FILE\n"
                    "       [--alpha X] [--beta Y] [--gen-a SEED] [--gen-b SEED] [--describe]\n"
-                   "       [--shard MODE:RANK/NRANKS] [--time ITERS] [--device N]\n"
+                   "       [--shard MODE:RANK/NRANKS] [--ngpu N [--shard-on MODE]] [--time ITERS] [--device N]\n"
                    "       ctc_contract --permute IN=OUT --extents ... [--dtype T] --a FILE --out FILE\n");
             return 0;
         }
@@ -188,6 +191,98 @@ int main(int argc, char **argv)
     if (!opt.count("out")) die("--out is required");
     const double alpha = opt.count("alpha") ? atof(opt["alpha"].c_str()) : 1.0;
     const double beta = opt.count("beta") ? atof(opt["beta"].c_str()) : 0.0;
+
+    const int ngpu = opt.count("ngpu") ? atoi(opt["ngpu"].c_str()) : 1;
+    if (ngpu < 1) die("bad --ngpu");
+    if (ngpu > 1) {
+        // Free-mode sharding inside one process (the engine runs ONE command per plugin step): rank r
+        // computes slab r of the chosen mode on device r (devices are shared round-robin when the node
+        // has fewer than N), and the slabs of C, which are disjoint, are merged on the host.
+        if (opt.count("shard")) die("--ngpu and --shard exclude each other");
+        const std::string a_modes = spec.substr(0, comma), b_modes = spec.substr(comma + 1, arrow - comma - 1);
+        const std::string c_modes = spec.substr(arrow + alen);
+        auto is_free = [&](char ch) { return (a_modes.find(ch) != std::string::npos) != (b_modes.find(ch) != std::string::npos); };
+        char mode = 0;
+        if (opt.count("shard-on") && opt["shard-on"] != "auto") {
+            mode = opt["shard-on"][0];
+            if (c_modes.find(mode) == std::string::npos || !is_free(mode)) die("--shard-on: not a free mode of this contraction");
+        } else {
+            for (char ch : c_modes)  // the slowest free mode of C that divides evenly
+                if (is_free(ch) && extents[names.find(ch)] % ngpu == 0) { mode = ch; break; }
+            if (!mode) die("--ngpu: no free mode whose extent is a multiple of the GPU count");
+        }
+        const int64_t e_m = extents[names.find(mode)];
+        if (e_m % ngpu != 0) die("--ngpu: the extent of the sharded mode must be a multiple of the GPU count");
+        size_t s_m = 1;  // stride of the mode in packed C
+        for (size_t i = c_modes.find(mode) + 1; i < c_modes.size(); ++i) s_m *= (size_t)extents[names.find(c_modes[i])];
+        std::vector<char> hA, hB;
+        if (!opt.count("gen-a")) { if (!opt.count("a")) die("--a or --gen-a is required"); hA = read_file(opt["a"], na * es); }
+        if (!opt.count("gen-b")) { if (!opt.count("b")) die("--b or --gen-b is required"); hB = read_file(opt["b"], nb * es); }
+        std::vector<char> hC(nc * es, 0);
+        if (beta != 0.0) hC = read_file(opt["out"], nc * es);
+        const int ndev = ctc_tc_device_count();
+        std::vector<std::string> errors((size_t)ngpu);
+        std::vector<double> rank_ms((size_t)ngpu, 0.0);
+        auto worker = [&](int r) {
+            auto fail = [&](const std::string &m) { errors[(size_t)r] = m; };
+            if (hipSetDevice(r % ndev) != hipSuccess) return fail("hipSetDevice");
+            ctc_tc_plan *slab = nullptr;
+            int64_t oa = 0, ob = 0, oc = 0;
+            if (ctc_tc_plan_shard(plan, mode, r, ngpu, &slab, &oa, &ob, &oc) < 0) return fail(std::string("shard: ") + ctc_tc_last_error());
+            void *dA = nullptr, *dB = nullptr, *dC = nullptr;
+            if (hipMalloc(&dA, na * es) != hipSuccess || hipMalloc(&dB, nb * es) != hipSuccess || hipMalloc(&dC, nc * es) != hipSuccess)
+                return fail("hipMalloc");
+            bool ok = true;
+            if (hA.empty()) ok = ok && ctc_tc_fill(dA, (int64_t)na, strtoull(opt["gen-a"].c_str(), nullptr, 0), 0, dtype, nullptr) >= 0;
+            else ok = ok && hipMemcpy(dA, hA.data(), na * es, hipMemcpyHostToDevice) == hipSuccess;
+            if (hB.empty()) ok = ok && ctc_tc_fill(dB, (int64_t)nb, strtoull(opt["gen-b"].c_str(), nullptr, 0), 0, dtype, nullptr) >= 0;
+            else ok = ok && hipMemcpy(dB, hB.data(), nb * es, hipMemcpyHostToDevice) == hipSuccess;
+            if (beta != 0.0) ok = ok && hipMemcpy(dC, hC.data(), nc * es, hipMemcpyHostToDevice) == hipSuccess;
+            if (!ok) return fail("operand upload");
+            const void *pa = static_cast<char *>(dA) + oa * es;
+            const void *pb = static_cast<char *>(dB) + ob * es;
+            void *pc = static_cast<char *>(dC) + oc * es;
+            if (opt.count("time")) {
+                double ms = 0;
+                if (ctc_tc_time_execute(slab, alpha, pa, pb, beta, pc, nullptr, 2, atoi(opt["time"].c_str()), &ms) < 0)
+                    return fail(std::string("time: ") + ctc_tc_last_error());
+                rank_ms[(size_t)r] = ms;
+                if (beta != 0.0 && hipMemcpy(dC, hC.data(), nc * es, hipMemcpyHostToDevice) != hipSuccess) return fail("C upload");
+            }
+            if (ctc_tc_execute(slab, alpha, pa, pb, beta, pc, nullptr) < 0) return fail(std::string("execute: ") + ctc_tc_last_error());
+            if (hipDeviceSynchronize() != hipSuccess) return fail("synchronize");
+            // the slab holds the runs [q * e_m + lo, q * e_m + hi) * s_m of C, q = 0, 1, ...: fetch the span
+            // that covers them and copy the runs into the host image (ranks touch disjoint elements)
+            const size_t lo = (size_t)r * (size_t)(e_m / ngpu), hi = lo + (size_t)(e_m / ngpu);
+            const size_t first = lo * s_m, end = nc - ((size_t)e_m - hi) * s_m;
+            std::vector<char> span((end - first) * es);
+            if (hipMemcpy(span.data(), static_cast<char *>(dC) + first * es, span.size(), hipMemcpyDeviceToHost) != hipSuccess)
+                return fail("copy C back");
+            const size_t period = (size_t)e_m * s_m, run = (hi - lo) * s_m;
+            for (size_t q = 0; q * period < nc; ++q)
+                memcpy(hC.data() + (q * period + first) * es, span.data() + q * period * es, run * es);
+            ctc_tc_plan_destroy(slab);
+            (void)hipFree(dA);
+            (void)hipFree(dB);
+            (void)hipFree(dC);
+        };
+        std::vector<std::thread> threads;
+        for (int r = 0; r < ngpu; ++r) threads.emplace_back(worker, r);
+        for (auto &th : threads) th.join();
+        for (int r = 0; r < ngpu; ++r)
+            if (!errors[(size_t)r].empty()) die("rank " + std::to_string(r) + ": " + errors[(size_t)r]);
+        if (opt.count("time")) {
+            double worst = 0;
+            for (double ms : rank_ms) worst = ms > worst ? ms : worst;
+            int64_t flops = 0;
+            ctc_tc_plan_get(plan, CTC_TC_Q_FLOPS, &flops, 1);
+            printf("ngpu %d mode %c devices %d max_device_ms %.4f tflops %.3f\n", ngpu, mode, ndev < ngpu ? ndev : ngpu, worst,
+                   (double)flops / worst * 1e-9);
+        }
+        write_file(opt["out"], hC.data(), nc * es);
+        ctc_tc_plan_destroy(plan);
+        return 0;
+    }
 
     void *dA = nullptr, *dB = nullptr, *dC = nullptr;
     hip_check(hipMalloc(&dA, na * es), "hipMalloc A");

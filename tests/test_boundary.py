@@ -53,6 +53,11 @@ def test_contract_plugin_command_line():
     cmds = eb.plugin_commands("contract", dict(spec="s", extents="e", input_a="a", input_b="b", output_c="c",
                                                shard="a:1/4", dtype="f32"))
     assert cmds[0].split()[-2:] == ["--shard", "a:1/4"] and "--dtype f32" in cmds[0]
+    cmds = eb.plugin_commands("contract", dict(spec="s", extents="e", input_a="a", input_b="b", output_c="c", ngpu="8"))
+    assert cmds[0].split()[-4:] == ["--ngpu", "8", "--shard-on", "auto"] and "--shard " not in cmds[0]
+    cmds = eb.plugin_commands("contract", dict(spec="s", extents="e", input_a="a", input_b="b", output_c="c", ngpu="4",
+                                               shard_on="i"))
+    assert cmds[0].split()[-4:] == ["--ngpu", "4", "--shard-on", "i"]
 
 
 def test_cli_command_composition():
@@ -73,6 +78,9 @@ def _engine_dry_run(plugin, params):
 def test_reference_engine_dry_run_equals_mirror():
     params = dict(spec="aeim,ebmj=abij", extents="a=64,b=64,e=64,i=64,j=64,m=64", input_a="/d/A", input_b="/d/B",
                   output_c="/d/C", alpha="2.5", shard="e:3/8")
+    assert _engine_dry_run("contract", params) == eb.plugin_commands("contract", params)
+    params = dict(spec="adij,bcdk=abcijk", extents="a=40,b=40,c=40,d=64,i=40,j=40,k=40", input_a="/d/A", input_b="/d/B",
+                  output_c="/d/C", ngpu="8", shard_on="a")
     assert _engine_dry_run("contract", params) == eb.plugin_commands("contract", params)
     params = dict(spec="adc,db=abc", extents="a=8,b=6,c=5,d=7", output_plan="/d/plan.txt")
     assert _engine_dry_run("contract_plan", params) == eb.plugin_commands("contract_plan", params)
@@ -134,6 +142,58 @@ def test_other_element_types_through_the_unchanged_engine(tmp_path, oracle, dtyp
         got, want = oracle.bf16_to_f32(got), oracle.bf16_to_f32(want)
     got, want = got.astype(np.float64), want.astype(np.float64)
     assert np.abs(got - want).max() <= tol * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("spec,ext,ngpu,shard_on", [
+    ("aeim,ebmj=abij", dict(a=8, b=6, e=5, i=7, j=4, m=3), "2", "auto"),   # a: slowest mode of C, contiguous slabs
+    ("aeim,ebmj=abij", dict(a=8, b=6, e=5, i=7, j=4, m=3), "3", "auto"),   # a does not divide by 3: b is taken
+    ("aeim,ebmj=abij", dict(a=5, b=6, e=5, i=7, j=4, m=3), "4", "j"),      # fastest mode of C: interleaved runs
+    ("adij,bcdk=abcijk", dict(a=4, b=3, c=2, d=16, i=6, j=5, k=8), "4", "k"),
+])
+def test_whole_contraction_on_several_gpus_through_the_unchanged_engine(tmp_path, oracle, spec, ext, ngpu, shard_on):
+    """--ngpu: one process, one host thread per slab of a free mode (ranks share the devices the box
+    has), slabs of C merged on the host; the file must equal the oracle's unsharded result."""
+    if not os.path.exists(ENGINE):
+        pytest.fail("oracle/_ref/execute_engine missing: run oracle/build_ref.sh where /root/reference exists")
+    ins, outm = spec.split("=")
+    la, lb = ins.split(",")
+    n = lambda m: int(np.prod([ext[c] for c in m]))  # noqa: E731
+    A = oracle.fill(n(la), 0xC7C0A)
+    B = oracle.fill(n(lb), 0xC7C0B)
+    A.tofile(tmp_path / "A.bin")
+    B.tofile(tmp_path / "B.bin")
+    extents = ",".join("%s=%d" % kv for kv in ext.items())
+    run = subprocess.run([ENGINE, eb.ENGINE_ROOT, "plugin", "contract", "--spec", spec, "--extents", extents,
+                          "--input_a", str(tmp_path / "A.bin"), "--input_b", str(tmp_path / "B.bin"),
+                          "--output_c", str(tmp_path / "C.bin"), "--ngpu", ngpu, "--shard_on", shard_on],
+                         capture_output=True, text=True, cwd=str(tmp_path))
+    assert os.path.exists(tmp_path / "C.bin"), run.stdout + run.stderr
+    got = np.fromfile(tmp_path / "C.bin", dtype=np.float64)
+    want = oracle.contract(spec.replace("=", "->"), ext, A, B)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+def test_several_gpus_with_beta_and_bad_requests(tmp_path, oracle):
+    ext = dict(a=6, d=7, c=5, b=4)
+    A = oracle.fill(6 * 7 * 5, 1)
+    B = oracle.fill(7 * 4, 2)
+    C0 = oracle.fill(6 * 4 * 5, 3)
+    A.tofile(tmp_path / "A.bin")
+    B.tofile(tmp_path / "B.bin")
+    C0.tofile(tmp_path / "C.bin")
+    base = [TOOL, "--spec", "adc,db=abc", "--extents", "a=6,d=7,c=5,b=4", "--a", str(tmp_path / "A.bin"), "--b",
+            str(tmp_path / "B.bin"), "--out", str(tmp_path / "C.bin")]
+    run = subprocess.run(base + ["--alpha", "0.5", "--beta", "-2", "--ngpu", "2", "--shard-on", "b"], capture_output=True, text=True)
+    assert run.returncode == 0, run.stderr
+    want = oracle.contract("adc,db->abc", ext, A, B, C=C0.copy(), alpha=0.5, beta=-2.0)
+    got = np.fromfile(tmp_path / "C.bin", dtype=np.float64)
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    for extra in (["--ngpu", "2", "--shard-on", "d"], ["--ngpu", "7"], ["--ngpu", "2", "--shard", "a:0/2"]):
+        run = subprocess.run(base + extra, capture_output=True, text=True)   # contracted mode; nothing divides by 7; both kinds of sharding
+        assert run.returncode != 0 and "ctc_contract:" in run.stderr, extra
 
 
 def _engine_workflow_dry_run(workflow, params, cwd):
