@@ -27,6 +27,7 @@
 #include "gemm_device.hpp"
 #include "kernels.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -547,16 +548,17 @@ template <int BT> __global__ void __launch_bounds__(256) splitk_fixup_bf16_kerne
 // each), one with the 256 tile (128 KB)
 template <int BT> int bf16_slots()
 {
-    static int cache[64] = {0};
+    static std::atomic<int> cache[64];  // 0: not queried yet; host threads of several devices may race here
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (cache[dev] == 0) {
+    if (cache[dev].load() == 0) {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_bf16_kernel<0, 0, BT>, 2 * BT, 0) != hipSuccess) return 0;
-        cache[dev] = cus * per_cu > 0 ? cus * per_cu : -1;
+        cache[dev].store(cus * per_cu > 0 ? cus * per_cu : -1);
     }
-    return cache[dev] > 0 ? cache[dev] : 0;
+    const int slots = cache[dev].load();
+    return slots > 0 ? slots : 0;
 }
 
 constexpr int kMinChunkTilesBf16 = 16;  // K-tiles (of 64) per chunk at least: shorter chunks cost more in the second launch than they save

@@ -24,6 +24,7 @@
 #include "kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -461,16 +462,17 @@ template <typename T, int BM> constexpr int tile_bk()
 // workgroup slots of the current device for one kernel instantiation (cached per device)
 template <typename K> int resident_slots(K kernel, int threads)
 {
-    static int cache[64] = {0};
+    static std::atomic<int> cache[64];  // 0: not queried yet; host threads of several devices may race here
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (cache[dev] == 0) {
+    if (cache[dev].load() == 0) {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) return 0;
-        cache[dev] = cus * per_cu > 0 ? cus * per_cu : -1;
+        cache[dev].store(cus * per_cu > 0 ? cus * per_cu : -1);
     }
-    return cache[dev] > 0 ? cache[dev] : 0;
+    const int slots = cache[dev].load();
+    return slots > 0 ? slots : 0;
 }
 
 // Splits the tiles of the last, partly filled round along K.  tiles = q * slots + tail:
