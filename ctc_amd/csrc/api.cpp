@@ -172,6 +172,10 @@ int get_permute_tables(int device, int rank, const int64_t *extents, const int *
     t.params.Y = pp.Y;
     t.params.O = pp.O;
     t.params.same_fast = pp.same_fast ? 1 : 0;
+    // A workgroup walks four consecutive o values when that lengthens the contiguous runs on one
+    // side (the next o lies right behind the y run in the output, or behind the x run in the
+    // input); otherwise one, which measures 9 % faster (128^4 fp32 abdc <- abcd: 5.2 -> 5.7 TB/s).
+    t.params.o_per_block = (pp.O > 1 && (pp.out_o[1] == pp.Y || pp.in_o[1] == pp.X)) ? 4 : 1;
     for (int i = 0; i < 3; ++i) {
         const int64_t v = 8 >> i;  // elements per 16 bytes for 2-, 4-, 8-byte elements
         t.params.vec_ok[i] = (pp.fast_in_extent % v == 0 && pp.fast_out_extent % v == 0) ? 1 : 0;

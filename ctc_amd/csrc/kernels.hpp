@@ -133,6 +133,7 @@ struct PermuteParams {
     int64_t X = 1, Y = 1, O = 1;
     int same_fast = 0;  // 1: input and output share their fastest mode (row copy)
     int vec_ok[3] = {0, 0, 0};  // 16-byte vectors legal for 2-, 4-, 8-byte elements (index log2(size)-1)
+    int o_per_block = 4;        // consecutive o values one workgroup of the vector kernel walks
 };
 hipError_t launch_permute(int elem_size, const PermuteParams &p, hipStream_t stream);
 

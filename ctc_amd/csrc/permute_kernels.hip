@@ -14,8 +14,8 @@
 // the row's vx, which makes both the writes (8 lanes: 8 different chunks) and the
 // reads (16 lanes of one row: 16 different chunks) bank-conflict free without padding.
 // In the store phase 16 neighbouring lanes write 256 contiguous bytes of the output.
-// A workgroup walks several consecutive `o` values with the same (x, y) patch so the
-// table entries are fetched once.
+// A workgroup walks o_per_block consecutive `o` values with the same (x, y) patch (the host
+// picks 4 when that lengthens the contiguous runs of one side, else 1).
 //
 // Scalar kernel: the same patch scheme with element accesses and a padded LDS tile,
 // for extents or strides that do not allow 16-byte vectors.
@@ -30,16 +30,12 @@ namespace {
 
 constexpr int kTile = 64;
 constexpr int kThreads = 256;
-#ifndef CTC_PERM_OPB
-#define CTC_PERM_OPB 4
-#endif
 // bit 0: non-temporal loads, bit 1: non-temporal stores.  The output of a permutation is not
 // read again by the kernel, and streaming stores gain 4 % on the 128^4 reversal (4.98 -> 5.18 TB/s);
 // non-temporal loads change nothing.
 #ifndef CTC_PERM_NT
 #define CTC_PERM_NT 2
 #endif
-constexpr int kOPerBlock = CTC_PERM_OPB;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -83,8 +79,8 @@ __global__ void __launch_bounds__(kThreads) permute_vec_kernel(const PermutePara
         out_xo[r] = p.out_x[x < p.X ? x : 0];
     }
 
-    const int64_t o_begin = ob * kOPerBlock;
-    const int64_t o_end = o_begin + kOPerBlock < p.O ? o_begin + kOPerBlock : p.O;
+    const int64_t o_begin = ob * p.o_per_block;
+    const int64_t o_end = o_begin + p.o_per_block < p.O ? o_begin + p.o_per_block : p.O;
     for (int64_t o = o_begin; o < o_end; ++o) {
         const E *in = static_cast<const E *>(p.in) + p.in_o[o] + in_xo;
         E *out = static_cast<E *>(p.out) + p.out_o[o] + out_yo;
@@ -262,7 +258,8 @@ template <typename E> hipError_t launch_permute_t(const PermuteParams &p, hipStr
     } else if (vec) {
         constexpr int T = 16 * V;
         const int64_t ntx = (p.X + T - 1) / T, nty = (p.Y + T - 1) / T;
-        const int64_t no = (p.O + kOPerBlock - 1) / kOPerBlock;
+        if (p.o_per_block < 1) return hipErrorInvalidValue;
+        const int64_t no = (p.O + p.o_per_block - 1) / p.o_per_block;
         const int64_t blocks = ntx * nty * no;
         if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
         hipLaunchKernelGGL((permute_vec_kernel<E>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, (int)ntx,
