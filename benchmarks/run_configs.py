@@ -16,6 +16,12 @@ import torch  # noqa: E402
 import ctc_amd  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
+# dense MFMA peaks of MI355X per element type, TFLOP/s (fp64: public datasheet; the others: the guide's dense figures)
+MFMA_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3, "bf16": 2500.0}
+
+
+def roofline(bound, achieved, peak, unit):
+    return {"bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4)}
 DEV = torch.device("cuda:0")
 
 
@@ -44,7 +50,8 @@ def permute_case(shape, perm, dtype=torch.float32, name=None):
                       "ms": round(ms, 4), "GB/s": round(nbytes / ms * 1e-6, 1),
                       "frac_hbm_peak": round(nbytes / ms * 1e-6 / HBM_PEAK_GBS, 4),
                       "d2d_copy_GB/s": round(nbytes / ms_copy * 1e-6, 1),
-                      "algorithmic_bytes": nbytes}))
+                      "algorithmic_bytes": nbytes,
+                      "roofline": roofline("hbm", nbytes / ms * 1e-6, HBM_PEAK_GBS, "GB/s")}))
 
 
 def contraction_case(spec, ext, dtype, name, ttgt=False):
@@ -65,7 +72,12 @@ def contraction_case(spec, ext, dtype, name, ttgt=False):
         ms = plan.time(A, B, C, warmup=3, iters=10)
     nbytes = (A.numel() + B.numel() + C.numel()) * A.element_size()
     s = plan.summary()
-    print(json.dumps({"workload": name, "path": "ttgt" if ttgt else "fused", "ms": round(ms, 4),
+    # the roof that bounds the contraction: HBM when moving its operands once takes longer than its MFMAs
+    t_mfma = plan.flops / (MFMA_PEAK_TFLOPS[dtype] * 1e9)
+    t_hbm = nbytes / (HBM_PEAK_GBS * 1e6)
+    roof = (roofline("hbm", nbytes / ms * 1e-6, HBM_PEAK_GBS, "GB/s") if t_hbm > t_mfma
+            else roofline("mfma", plan.flops / ms * 1e-9, MFMA_PEAK_TFLOPS[dtype], "TFLOP/s"))
+    print(json.dumps({"workload": name, "path": "ttgt" if ttgt else "fused", "ms": round(ms, 4), "roofline": roof,
                       "TFLOP/s": round(plan.flops / ms * 1e-9, 3), "GB/s": round(nbytes / ms * 1e-6, 1),
                       "frac_hbm_peak": round(nbytes / ms * 1e-6 / HBM_PEAK_GBS, 4),
                       "gemm": [s["M"], s["N"], s["K"], s["batch_count"]], "tile": s["tile"],
