@@ -1,7 +1,7 @@
 """Secondary measurements (BASELINE configs 3 and 5, plus kernel variants).  The headline
 (config 2) lives in bench.py; this script prints one JSON line per measurement.
 
-  python benchmarks/run_configs.py [permute] [adversarial] [f32] [bf16] [six] [small] [fastr] [sw] [ttgt]
+  python benchmarks/run_configs.py [permute] [adversarial] [f32] [bf16] [six] [small] [fastr|fastr_large] [sw] [ttgt]
 """
 import json
 import os
@@ -148,11 +148,13 @@ def main():
                               "launches": 1, "ms": round(ms, 4), "TFLOP/s": round(flops / ms * 1e-9, 3),
                               "GB/s": round(nbytes / ms * 1e-6, 1), "flops": flops,
                               "one_launch_per_problem_ms_extrapolated_from_%d" % sub: round(per_launch_ms, 2)}))
-    if "fastr" in what:
+    if "fastr" in what or "fastr_large" in what:
         import numpy as np
         from ctc_amd import fastr
         from oracle import fastr as ofastr
-        b = ofastr.make_batch(seed=0xFA57)  # 32 regions x U{1..8} consensuses x U{20..200} reads, read length 100
+        # 32 regions x U{1..8} consensuses x U{20..200} reads, read length 100; fastr_large: 256 regions,
+        # enough workgroups to fill the chip several times over
+        b = ofastr.make_batch(seed=0xFA57, n_regions=256 if "fastr_large" in what else 32)
         d = fastr.DeviceBatch(b, DEV)
         ms = time_ms(lambda: d.run(), warmup=3, iters=20)
         t0 = time.perf_counter()
@@ -172,7 +174,7 @@ def main():
                 cons += 1
             read_off += b["alt_reads"][t]
         in_bytes = b["ref"].size + b["read_seq"].size + b["quals"].size + 8 * b["read_len"].size + 8 * d.n_pairs
-        print(json.dumps({"workload": "config5(ii) FASTR scoring batch: 32 regions, %d (read, consensus) pairs" % d.n_pairs,
+        print(json.dumps({"workload": "config5(ii) FASTR scoring batch: %d regions, %d (read, consensus) pairs" % (len(b["n_consensus"]), d.n_pairs),
                           "ms": round(ms, 4), "pairs/s": round(d.n_pairs / ms * 1e3), "bit_exact_vs_oracle": exact,
                           "full_scan_byte_compares": compares,
                           "full_scan_Gcompare/s": round(compares / ms * 1e-6, 1),
