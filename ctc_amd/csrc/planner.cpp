@@ -143,6 +143,7 @@ void choose_tile(Plan &p)
         if (big) { t.bm = 256; t.bn = 256; t.threads = 512; }
     }
     t.group = 8;
+    if (const char *g = getenv("CTC_TC_GROUP")) { if (atoi(g) > 0) t.group = atoi(g); }
     p.tile = t;
 }
 
