@@ -128,3 +128,56 @@ def test_random_permutations_are_bit_exact(cuda):
         ctc_amd.permute(x, perm, out=out)
         assert np.array_equal(out.cpu().numpy(), np.transpose(host, perm)), (shape, perm, ndt)
         done += 1
+
+
+def test_random_shardings_against_oracle(cuda, oracle):
+    """Random contractions cut into 2..4 slabs along a random mode (free: disjoint slabs of C written in
+    place; contracted: partial results summed; batch: disjoint slabs), every slab executed through its
+    own sub-plan with the full tensors' strides, against the oracle's unsharded result."""
+    rng = random.Random(0x5AAD)
+    want_cases = max(20, int(os.environ.get("CTC_FUZZ_CASES", "120")) // 3)
+    done = 0
+    kinds = set()
+    while done < want_cases:
+        c = _case(rng)
+        if c is None:
+            continue
+        spec, ext, dtype, alpha, _beta = c
+        if dtype == "bf16":
+            continue  # partial sums of a contracted mode would be rounded to bf16 before they are added
+        ins, outm = spec.split("->")
+        la, lb = ins.split(",")
+        nr = rng.choice([2, 3, 4])
+        modes = [m for m in ext if ext[m] % nr == 0 and ext[m] >= nr]
+        if not modes:
+            continue
+        mode = rng.choice(modes)
+        size = lambda m: int(np.prod([ext[x] for x in m])) if m else 1  # noqa: E731
+        code = CODE[dtype]
+        A = oracle.fill(size(la), 5000 + done, code)
+        B = oracle.fill(size(lb), 6000 + done, code)
+        want = oracle.contract(spec, ext, A, B, alpha=alpha, dtype=code).astype(np.float64)
+        tdt = torch.float64 if dtype == "f64" else torch.float32
+        dA, dB = torch.from_numpy(A).to(cuda), torch.from_numpy(B).to(cuda)
+        full = ctc_amd.Plan(spec, ext, dtype)
+        contracted = mode not in outm
+        kinds.add("contracted" if contracted else "batch" if (mode in la and mode in lb) else "free")
+        if contracted:
+            acc = torch.zeros(size(outm), dtype=torch.float64, device=cuda)
+            for r in range(nr):
+                sh, oa, ob, oc = full.shard(mode, r, nr)
+                part = torch.full((size(outm),), float("nan"), dtype=tdt, device=cuda)
+                sh.execute(dA[oa:], dB[ob:], part[oc:], alpha=alpha)
+                acc += part.double()
+            got = acc.cpu().numpy()
+        else:
+            dC = torch.full((size(outm),), float("nan"), dtype=tdt, device=cuda)
+            for r in range(nr):
+                sh, oa, ob, oc = full.shard(mode, r, nr)
+                sh.execute(dA[oa:], dB[ob:], dC[oc:], alpha=alpha)
+            got = dC.cpu().numpy().astype(np.float64)
+        assert np.isfinite(got).all(), (spec, ext, dtype, mode, nr)
+        err = np.abs(got - want).max()
+        assert err <= TOL[dtype] * max(np.abs(want).max(), 1e-300), (spec, ext, dtype, mode, nr, err)
+        done += 1
+    assert kinds >= {"free", "contracted"}, kinds
