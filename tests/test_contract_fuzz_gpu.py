@@ -181,3 +181,54 @@ def test_random_shardings_against_oracle(cuda, oracle):
         assert err <= TOL[dtype] * max(np.abs(want).max(), 1e-300), (spec, ext, dtype, mode, nr, err)
         done += 1
     assert kinds >= {"free", "contracted"}, kinds
+
+
+def _padded(modes, ext, rng):
+    """Strides (in elements, per operand position) of a tensor whose modes are padded by random amounts,
+    and the number of elements its buffer needs."""
+    pad = {m: ext[m] + rng.choice([0, 0, 1, 2, 5]) for m in modes}
+    strides, s = [0] * len(modes), 1
+    for i in range(len(modes) - 1, -1, -1):
+        strides[i] = s
+        s *= pad[modes[i]]
+    need = 1 + sum((ext[m] - 1) * st for m, st in zip(modes, strides))
+    return strides, need
+
+
+def test_random_strided_operands_against_oracle(cuda, oracle):
+    """Padded (non-packed) strides on A, B and C and base pointers shifted off the 16-byte grid."""
+    rng = random.Random(0x57D1DE)
+    want_cases = max(20, int(os.environ.get("CTC_FUZZ_CASES", "120")) // 3)
+    done = 0
+    while done < want_cases:
+        c = _case(rng)
+        if c is None:
+            continue
+        spec, ext, dtype, alpha, beta = c
+        if dtype == "bf16":
+            continue
+        ins, outm = spec.split("->")
+        la, lb = ins.split(",")
+        sa, na = _padded(la, ext, rng)
+        sb, nb = _padded(lb, ext, rng)
+        sc, nc = _padded(outm, ext, rng)
+        if max(na, nb, nc) > 8_000_000:
+            continue
+        code = CODE[dtype]
+        shift = [rng.choice([0, 0, 1, 3]) for _ in range(3)]
+        A = oracle.fill(na + shift[0], 7000 + done, code)
+        B = oracle.fill(nb + shift[1], 8000 + done, code)
+        C0 = oracle.fill(nc + shift[2], 9000 + done, code)
+        want = oracle.contract(spec, ext, A[shift[0]:], B[shift[1]:], C=C0[shift[2]:].copy(), alpha=alpha, beta=beta,
+                               dtype=code, strides_a=sa, strides_b=sb, strides_c=sc)
+        plan = ctc_amd.Plan(spec, ext, dtype, strides_a=sa, strides_b=sb, strides_c=sc)
+        dC = torch.from_numpy(C0.copy()).to(cuda)
+        plan.execute(torch.from_numpy(A).to(cuda)[shift[0]:], torch.from_numpy(B).to(cuda)[shift[1]:], dC[shift[2]:],
+                     alpha=alpha, beta=beta)
+        got = dC.cpu().numpy()[shift[2]:].astype(np.float64)
+        want = want.astype(np.float64)
+        # elements in the padding are never touched; elements of C are compared where they exist
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        err = np.abs(got - want).max()
+        assert err <= TOL[dtype] * max(np.abs(want).max(), 1e-300), (spec, ext, dtype, sa, sb, sc, shift, err)
+        done += 1
