@@ -31,6 +31,7 @@ Q_SWAPPED, Q_EXEC_BATCH, Q_EXEC_M, Q_EXEC_N, Q_EXEC_K = 10, 11, 12, 13, 14
 Q_GEMM_DIMS, Q_TILE = 15, 16
 Q_ROW_A, Q_K_A, Q_K_B, Q_COL_B, Q_ROW_C, Q_COL_C, Q_BAT_A, Q_BAT_B, Q_BAT_C = range(17, 26)
 Q_FLOPS = 26
+Q_SCHEDULE = 27
 
 
 class CtcError(RuntimeError):

@@ -397,6 +397,21 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
     case CTC_TC_Q_BAT_B: return copy_out(p.bat_b, out, cap);
     case CTC_TC_Q_BAT_C: return copy_out(p.bat_c, out, cap);
     case CTC_TC_Q_FLOPS: v.push_back(2 * p.M * p.N * p.K * p.batch); break;
+    case CTC_TC_Q_SCHEDULE: {
+        // needs a device: the split of the last round of tiles depends on the resident workgroups
+        if (p.kernel != ctc::kKernelGemm) return fail(CTC_TC_EUNSUPPORTED, "not a tiled GEMM plan");
+        int device = 0;
+        int rc = current_device(device);
+        if (rc) return rc;
+        ctc::GemmParams g;
+        g.M = p.M; g.N = p.N; g.K = p.K;
+        g.batch = (int)p.batch;
+        ctc::GemmSchedule sch;
+        hipError_t e = ctc::schedule_gemm(p.dtype, p.layout_a, p.layout_b, p.tile.bm, p.tile.bn, g, &sch);
+        if (e != hipSuccess) return fail_hip(e, "contraction schedule");
+        v = {sch.nbm, sch.nbn, sch.dp_tiles, sch.tail_tiles, sch.split, (int64_t)sch.ws_bytes};
+        break;
+    }
     default: return fail(CTC_TC_EINVAL, "unknown query");
     }
     return copy_out(v, out, cap);

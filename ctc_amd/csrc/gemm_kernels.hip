@@ -459,8 +459,10 @@ template <typename T, int BM> constexpr int tile_bk()
 #endif
 }
 
-// workgroup slots of the current device for one kernel instantiation (cached per device)
-template <typename K> int resident_slots(K kernel, int threads)
+// workgroup slots of the current device for one kernel instantiation (cached per device).  Tag
+// names the instantiation: every gemm_kernel has the same function TYPE, so a cache keyed by the
+// type of `kernel` alone would be shared by all of them.
+template <typename Tag, typename K> int resident_slots(K kernel, int threads)
 {
     static std::atomic<int> cache[64];  // 0: not queried yet; host threads of several devices may race here
     int dev = 0;
@@ -474,6 +476,7 @@ template <typename K> int resident_slots(K kernel, int threads)
     const int slots = cache[dev].load();
     return slots > 0 ? slots : 0;
 }
+template <typename T, int LA, int LB, int BM, int BN> struct KernelTag {};
 
 // Splits the tiles of the last, partly filled round along K.  tiles = q * slots + tail:
 // the q full rounds stay data-parallel; each tail tile is cut into floor(slots / tail)
@@ -494,7 +497,7 @@ hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
     s.tail_tiles = 0;
     s.ws_bytes = 0;
     static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
-    const int slots = resident_slots(gemm_kernel<T, LA, LB, BM, BN, BK, WM, WN>, 64 * WM * WN);
+    const int slots = resident_slots<KernelTag<T, LA, LB, BM, BN>>(gemm_kernel<T, LA, LB, BM, BN, BK, WM, WN>, 64 * WM * WN);
     const int nk = (int)((p.K + BK - 1) / BK);
     if (!no_split && slots > 0 && p.batch == 1) {
         const int tail = (int)(tiles % slots);

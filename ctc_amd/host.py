@@ -145,6 +145,13 @@ class Plan:
     def flops(self):
         return self.get(_lib.Q_FLOPS)[0]
 
+    def schedule(self):
+        """How the current device will run the tiles (needs a GPU): tiles run whole, tiles of the last,
+        partly filled round cut along K, chunks per such tile, workspace bytes."""
+        nbm, nbn, whole, tail, split, ws = self.get(_lib.Q_SCHEDULE)
+        return {"tile_rows": nbm, "tile_cols": nbn, "whole_tiles": whole, "tail_tiles": tail, "split": split,
+                "workspace_bytes": ws}
+
     # ---- sharding ----------------------------------------------------------
     def shard(self, mode, rank, nranks):
         """Sub-plan for slab `rank` of `nranks` along `mode`, plus element offsets into A, B, C."""

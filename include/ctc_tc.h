@@ -93,7 +93,9 @@ enum ctc_tc_query {
     CTC_TC_Q_BAT_A = 23,
     CTC_TC_Q_BAT_B = 24,
     CTC_TC_Q_BAT_C = 25,
-    CTC_TC_Q_FLOPS = 26        /* {2*M*N*K*batch} */
+    CTC_TC_Q_FLOPS = 26,       /* {2*M*N*K*batch} */
+    CTC_TC_Q_SCHEDULE = 27     /* needs a HIP device: {tile rows, tile columns, tiles run whole, tiles of the last round
+                                  that are cut along K, chunks per such tile, workspace bytes} */
 };
 
 /* operand layouts reported in CTC_TC_Q_TILE */

@@ -312,3 +312,22 @@ def test_offsets_beyond_2_31_elements(cuda):
         assert (got - want).abs().max() <= 1e-5 * want.abs().max(), r
     del dC
     torch.cuda.empty_cache()
+
+
+def test_schedule_does_not_depend_on_earlier_plans(cuda):
+    """The split of the last round of tiles is computed from the resident workgroups of the kernel
+    instantiation that will run; a small-tile plan scheduled first (four workgroups per CU) must not
+    change what a large-tile plan gets (two per CU), in either element type."""
+    big_ext = dict(a=56, b=56, i=56, j=56, e=56, m=56)       # 25 x 25 tiles of 128: one round of 512 + 113
+    small_ext = dict(a=48, b=48, i=48, j=48, e=48, m=48)     # 64 x 64 tiles
+    for dt in ("f64", "f32"):
+        small = ctc_amd.Plan("aeim,ebmj->abij", small_ext, dt)
+        assert tuple(small.summary()["tile"][:2]) == (64, 64)
+        s_small = small.schedule()
+        big = ctc_amd.Plan("aeim,ebmj->abij", big_ext, dt)
+        assert tuple(big.summary()["tile"][:2]) == (128, 128)
+        s = big.schedule()
+        assert s["tile_rows"] * s["tile_cols"] == 625
+        slots_big = s["whole_tiles"]  # one full round
+        assert s["tail_tiles"] == 625 - slots_big and s["tail_tiles"] > 0 and s["split"] >= 2, (dt, s, s_small)
+        assert slots_big % 256 == 0 and slots_big <= 512, (dt, s)   # two workgroups per CU at most for this tile

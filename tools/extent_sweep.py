@@ -1,0 +1,28 @@
+"""CCSD-style contraction abij = aeim,ebmj at a range of extents: where the tile choice and the
+split along K hold the fp64 / fp32 rate and where they do not.   python tools/extent_sweep.py [f64|f32]"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctc_amd  # noqa: E402
+
+dt = sys.argv[1] if len(sys.argv) > 1 else "f64"
+tdt = {"f64": torch.float64, "f32": torch.float32}[dt]
+dev = torch.device("cuda:0")
+sizes = [int(x) for x in sys.argv[2:]] or [16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96]
+for n in sizes:
+    ext = dict(a=n, b=n, i=n, j=n, e=n, m=n)
+    A = torch.empty(n ** 4, dtype=tdt, device=dev)
+    B = torch.empty(n ** 4, dtype=tdt, device=dev)
+    C = torch.empty(n ** 4, dtype=tdt, device=dev)
+    ctc_amd.fill(A, 1)
+    ctc_amd.fill(B, 2)
+    plan = ctc_amd.Plan("aeim,ebmj->abij", ext, dt)
+    for _ in range(20 if n < 64 else 3):
+        plan.execute(A, B, C)
+    ms = plan.time(A, B, C, warmup=3, iters=20 if n < 64 else 5)
+    s = plan.summary()
+    print(json.dumps({"extent": n, "gemm": n * n, "tile": s["tile"], "ms": round(ms, 4), "TFLOP/s": round(plan.flops / ms * 1e-9, 2)}), flush=True)
