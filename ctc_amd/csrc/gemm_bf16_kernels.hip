@@ -611,8 +611,21 @@ hipError_t schedule_gemm_bf16(int la, int lb, int bm, const GemmParams &p, GemmS
     if (!no_split && slots > 0 && p.batch == 1) {
         const int tail = (int)(tiles % slots);
         if (tail > 0) {
-            int f = slots / tail;
-            if (f > nk / kMinChunkTilesBf16) f = nk / kMinChunkTilesBf16;
+            // f chunks per tail tile take ceil(tail * f / slots) rounds of (nk / f + overhead) K-tile
+            // times (overhead of a chunk: kMinChunkTilesBf16 K-tiles); f minimises that, as in the
+            // f64 / f32 scheduler
+            int fmax = nk / kMinChunkTilesBf16;
+            if (fmax > 64) fmax = 64;
+            int f = 1;
+            double best = (double)nk;
+            for (int c = 2; c <= fmax; ++c) {
+                const double rounds = (double)(((int64_t)tail * c + slots - 1) / slots);
+                const double cost = rounds * ((double)nk / c + kMinChunkTilesBf16);
+                if (cost < best * 0.98) {
+                    best = cost;
+                    f = c;
+                }
+            }
             if (f >= 2) {
                 s.tail_tiles = tail;
                 s.dp_tiles = (int)tiles - tail;

@@ -319,7 +319,7 @@ def test_schedule_does_not_depend_on_earlier_plans(cuda):
     instantiation that will run; a small-tile plan scheduled first (four workgroups per CU) must not
     change what a large-tile plan gets (two per CU), in either element type."""
     big_ext = dict(a=56, b=56, i=56, j=56, e=56, m=56)       # 25 x 25 tiles of 128: one round of 512 + 113
-    small_ext = dict(a=48, b=48, i=48, j=48, e=48, m=48)     # 64 x 64 tiles
+    small_ext = dict(a=32, b=32, i=32, j=32, e=32, m=32)     # 64 x 64 tiles
     for dt in ("f64", "f32"):
         small = ctc_amd.Plan("aeim,ebmj->abij", small_ext, dt)
         assert tuple(small.summary()["tile"][:2]) == (64, 64)
