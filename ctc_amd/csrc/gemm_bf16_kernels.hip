@@ -448,6 +448,50 @@ __global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(co
             }
         return;
     }
+    if (p.c_vec >= 8 && beta == 0.f) {
+        // The tile goes through LDS (the operand stages are free now) and leaves in 16-byte vectors
+        // along the rows of C: 32 (16 for the 128 tile) neighbouring lanes write one whole tile row
+        // of 2 BT bytes, against 32-byte pieces per row when a quad stores its 4 x 4 block directly
+        // (16384 x 16384 x 256: 0.94 TB/s of C).  Image [row][BT] bf16, its 16-byte chunks XOR-ed
+        // with the row so that the quads' 8-byte writes of sixteen rows spread over the banks.
+        typedef gemm_detail::Traits<float> Tr;
+        constexpr int NTH = 2 * BT;         // threads of the workgroup
+        constexpr int CPR = BT / 8;         // 16-byte chunks per tile row
+        constexpr int VPT = BT * CPR / NTH;  // vectors per thread on the way out
+        const int out_chunk = t % CPR, out_row0 = t / CPR;
+        // this thread's C offsets, requested before the barrier
+        int64_t ro[VPT];
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int64_t m = m0 + out_row0 + v * (NTH / CPR);
+            ro[v] = m < p.M ? p.row_c[m] : INT64_MIN;
+        }
+        const int64_t nv = n0 + 8 * out_chunk;
+        const int64_t co = nv < p.N ? p.col_c[nv] : INT64_MIN;
+        __syncthreads();  // every wave has read its last fragments
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm0 + 16 * i + Tr::cvec_row(lane, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f4_t v = Tr::cvec(acc[i][j], lane, 0);  // every lane takes part in the exchange
+                const int col = wn0 + 16 * j + (frow & ~3);
+                u2_t w;
+                w[0] = (unsigned)f32_to_bf16(alpha * v[0]) | ((unsigned)f32_to_bf16(alpha * v[1]) << 16);
+                w[1] = (unsigned)f32_to_bf16(alpha * v[2]) | ((unsigned)f32_to_bf16(alpha * v[3]) << 16);
+                const int chunk = (col >> 3) ^ (row & (CPR - 1));
+                *reinterpret_cast<u2_t *>(smem + row * (2 * BT) + 16 * chunk + 2 * (col & 7)) = w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int row = out_row0 + v * (NTH / CPR);
+            const u4_t w = *reinterpret_cast<const u4_t *>(smem + row * (2 * BT) + 16 * (out_chunk ^ (row & (CPR - 1))));
+            if (ro[v] != INT64_MIN && co != INT64_MIN) *reinterpret_cast<u4_t *>(C + ro[v] + co) = w;
+        }
+        return;
+    }
     if (p.c_vec >= 4) {
         // 8-byte stores: a 4 x 4 transpose inside each quad leaves lane q with four
         // neighbouring columns of row register q
@@ -572,6 +616,9 @@ template <int LA, int LB, int BT>
 hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     GemmParams q = p;
+    // diagnostic: CTC_TC_BF16_DIRECT_STORE keeps the quads' direct 8-byte stores (no pass through LDS)
+    static const bool direct_store = getenv("CTC_TC_BF16_DIRECT_STORE") != nullptr;
+    if (direct_store && q.c_vec > 4) q.c_vec = 4;
     q.nbm = sch.nbm;
     q.nbn = sch.nbn;
     q.dp_tiles = sch.dp_tiles;
