@@ -202,6 +202,32 @@ __global__ void __launch_bounds__(kThreads) permute_rows_vec_kernel(const Permut
     }
 }
 
+// Rows shorter than a workgroup's kThreads * U slots: a workgroup copies `rows` whole rows, slot s of
+// the workgroup being unit s % units of its row s / units (a unit is a 16-byte vector or, without
+// vectors, an element).  With one row per workgroup a 224-byte row kept 14 of 256 threads busy
+// (0.8 TB/s on 24 x 40 x 32 x 48 x 56 fp32 with the last mode in place; 1.5 TB/s with 448-byte rows).
+template <typename E, typename UNIT, int U>
+__global__ void __launch_bounds__(kThreads) permute_short_rows_kernel(const PermuteParams p, int units, int rows)
+{
+    const int64_t o0 = (int64_t)blockIdx.x * rows;
+    UNIT v[U];
+    int64_t dst[U];
+#pragma unroll
+    for (int r = 0; r < U; ++r) {
+        const int s = threadIdx.x + r * kThreads;
+        const int row = s / units, x = s - row * units;
+        const int64_t o = o0 + row;
+        dst[r] = -1;
+        if (row < rows && o < p.O) {
+            v[r] = reinterpret_cast<const UNIT *>(static_cast<const E *>(p.in) + p.in_o[o])[x];
+            dst[r] = p.out_o[o] * (int64_t)sizeof(E) + (int64_t)x * (int64_t)sizeof(UNIT);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < U; ++r)
+        if (dst[r] >= 0) *reinterpret_cast<UNIT *>(static_cast<char *>(p.out) + dst[r]) = v[r];
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 {
     uint64_t z = x + 0x9E3779B97F4A7C15ULL;
@@ -251,7 +277,18 @@ template <typename E> hipError_t launch_permute_t(const PermuteParams &p, hipStr
         const int64_t chunks = (units + per_block - 1) / per_block;
         const int64_t blocks = chunks * p.O;
         if (blocks <= 0 || blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
-        if (vec)
+        if (2 * units <= per_block) {
+            // several rows per workgroup
+            const int rows = (int)(per_block / units);
+            const int64_t nb = (p.O + rows - 1) / rows;
+            if (nb > 0x7FFFFFFF) return hipErrorInvalidValue;
+            if (vec)
+                hipLaunchKernelGGL((permute_short_rows_kernel<E, u32x4, kRowsU>), dim3((unsigned)nb), dim3(kThreads), 0, stream, p,
+                                   (int)units, rows);
+            else
+                hipLaunchKernelGGL((permute_short_rows_kernel<E, E, 4>), dim3((unsigned)nb), dim3(kThreads), 0, stream, p,
+                                   (int)units, rows);
+        } else if (vec)
             hipLaunchKernelGGL((permute_rows_vec_kernel<E>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, (int)chunks);
         else
             hipLaunchKernelGGL((permute_rows_kernel<E>), dim3((unsigned)blocks), dim3(kThreads), 0, stream, p, (int)chunks);
