@@ -328,7 +328,8 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
     p.kernel = kKernelGemm;
     const bool c_unit_in_n = c_unit >= 0 && p.modes[c_unit].cls != kBatch && p.modes[c_unit].cls != kContracted;
     const bool b_unit_in_n = b_unit >= 0 && std::find(p.ex_n.begin(), p.ex_n.end(), b_unit) != p.ex_n.end();
-    if (dtype != kBF16 && p.M <= kSkinnyMaxM && p.M * p.K <= kSkinnyMaxMK && p.N >= 4096 && c_unit_in_n && b_unit_in_n) {
+    if (dtype != kBF16 && p.M <= kSkinnyMaxM && p.M * p.K <= kSkinnyMaxMK && p.N >= 4096 && c_unit_in_n && b_unit_in_n &&
+        getenv("CTC_TC_NO_SKINNY") == nullptr) {
         const int vb = vector_width(p, gb_modes, gb, b_unit, vmax);
         const int vc = vector_width(p, p.c_modes, sc, c_unit, vmax);
         if (vb == vmax && vc == vmax) {

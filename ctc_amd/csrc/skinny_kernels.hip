@@ -41,8 +41,10 @@ __device__ __forceinline__ void load_small_operand(T *sA, const SkinnyParams &p,
     __syncthreads();
 }
 
+// (at least four workgroups per CU: without the bound the MMAX = 8 instantiations are compiled to 256
+// registers, one wave per SIMD, and stream at 0.6 - 1.1 TB/s where MMAX = 4 and 16 reach 3 - 4)
 template <typename T, int MMAX>
-__global__ void __launch_bounds__(kThreads) skinny_same_kernel(const SkinnyParams p)
+__global__ void __launch_bounds__(kThreads, 4) skinny_same_kernel(const SkinnyParams p)
 {
     typedef typename VecT<T>::type vec_t;
     constexpr int V = VecT<T>::V;
