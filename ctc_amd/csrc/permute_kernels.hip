@@ -133,28 +133,41 @@ __global__ void __launch_bounds__(kThreads) permute_tiled_kernel(const PermutePa
     const E *in = static_cast<const E *>(p.in) + p.in_o[o];
     E *out = static_cast<E *>(p.out) + p.out_o[o];
 
+    // all sixteen row offsets first, then all sixteen loads in flight at once (a lookup followed by its
+    // load, row after row, left one or two loads in flight per thread: 1.6 TB/s)
+    constexpr int ROWS = kTile / 4;
     {
         const int64_t x = x0 + lx;
         const bool xok = x < p.X;
         const int64_t xoff = p.in_x[xok ? x : 0];
-#pragma unroll 4
-        for (int r = 0; r < kTile / 4; ++r) {
-            const int yy = ly + 4 * r;
-            const int64_t y = y0 + yy;
-            if (xok && y < p.Y) tile[yy][lx] = in[xoff + p.in_y[y]];
+        int64_t yo[ROWS];
+        E v[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t y = y0 + ly + 4 * r;
+            yo[r] = (xok && y < p.Y) ? p.in_y[y] : -1;
         }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+            if (yo[r] >= 0) v[r] = in[xoff + yo[r]];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+            if (yo[r] >= 0) tile[ly + 4 * r][lx] = v[r];
     }
     __syncthreads();
     {
         const int64_t y = y0 + lx;
         const bool yok = y < p.Y;
         const int64_t yoff = p.out_y[yok ? y : 0];
-#pragma unroll 4
-        for (int r = 0; r < kTile / 4; ++r) {
-            const int xx = ly + 4 * r;
-            const int64_t x = x0 + xx;
-            if (yok && x < p.X) out[yoff + p.out_x[x]] = tile[lx][xx];
+        int64_t xo[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int64_t x = x0 + ly + 4 * r;
+            xo[r] = (yok && x < p.X) ? p.out_x[x] : -1;
         }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+            if (xo[r] >= 0) out[yoff + xo[r]] = tile[lx][ly + 4 * r];
     }
 }
 
