@@ -568,12 +568,26 @@ template <int BT> __global__ void __launch_bounds__(256) splitk_fixup_bf16_kerne
         const int row = rblk * ROWS + rr;
         const int64_t m = (int64_t)tm * BM + row;
         if (m >= p.M) continue;
-        float s0 = 0.f, s1 = 0.f;
-        for (int c = 0; c < p.split; ++c) {
-            const float *src = slab0 + (int64_t)c * (BM * BN) + row * BN + 2 * cv;
-            s0 += src[0];
-            s1 += src[1];
+        // eight chunks at a time into separate sums (eight loads in flight); fixed order of additions
+        float a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a0[u] = a1[u] = 0.f;
+        int c = 0;
+        for (; c + 8 <= p.split; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float *src = slab0 + (int64_t)(c + u) * (BM * BN) + row * BN + 2 * cv;
+                a0[u] += src[0];
+                a1[u] += src[1];
+            }
         }
+        for (int u = 0; c < p.split; ++c, ++u) {
+            const float *src = slab0 + (int64_t)c * (BM * BN) + row * BN + 2 * cv;
+            a0[u] += src[0];
+            a1[u] += src[1];
+        }
+        const float s0 = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7]));
+        const float s1 = ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
         const int64_t ro = p.row_c[m];
         if (ok0) {
             float v = alpha * s0;
@@ -662,7 +676,7 @@ hipError_t schedule_gemm_bf16(int la, int lb, int bm, const GemmParams &p, GemmS
             // times (overhead of a chunk: kMinChunkTilesBf16 K-tiles); f minimises that, as in the
             // f64 / f32 scheduler
             int fmax = nk / kMinChunkTilesBf16;
-            if (fmax > 64) fmax = 64;
+            if (fmax > 1024) fmax = 1024;  // one tile with a very long K may use every slot
             int f = 1;
             double best = (double)nk;
             for (int c = 2; c <= fmax; ++c) {

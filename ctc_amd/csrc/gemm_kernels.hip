@@ -428,12 +428,27 @@ __global__ void __launch_bounds__(256) splitk_fixup_kernel(const GemmParams p)
         const int row = rblk * ROWS + rr;
         const int64_t m = (int64_t)tm * BM + row;
         if (m >= p.M) continue;
-        T s0 = 0, s1 = 0;
-        for (int c = 0; c < p.split; ++c) {
-            const T *src = slab0 + (int64_t)c * (BM * BN) + row * BN + 2 * cv;
-            s0 += src[0];
-            s1 += src[1];
+        // eight chunks at a time into separate sums: eight loads in flight instead of one (a tile cut
+        // several hundred ways otherwise spends longer here than in the GEMM); fixed order of additions
+        T a0[8], a1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a0[u] = a1[u] = 0;
+        int c = 0;
+        for (; c + 8 <= p.split; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const T *src = slab0 + (int64_t)(c + u) * (BM * BN) + row * BN + 2 * cv;
+                a0[u] += src[0];
+                a1[u] += src[1];
+            }
         }
+        for (int u = 0; c < p.split; ++c, ++u) {
+            const T *src = slab0 + (int64_t)c * (BM * BN) + row * BN + 2 * cv;
+            a0[u] += src[0];
+            a1[u] += src[1];
+        }
+        const T s0 = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7]));
+        const T s1 = ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
         const int64_t ro = p.row_c[m];
         if (ok0) {
             T v = alpha * s0;
@@ -489,7 +504,7 @@ constexpr int kMinChunkTiles = 8;
 inline int best_split(int64_t tail, int slots, int nk)
 {
     int fmax = nk / kMinChunkTiles;
-    if (fmax > 64) fmax = 64;
+    if (fmax > 1024) fmax = 1024;  // one tile with a very long K may use every slot
     int best_f = 1;
     double best = (double)nk;  // unsplit: one round of whole tiles, no workspace
     for (int f = 2; f <= fmax; ++f) {
