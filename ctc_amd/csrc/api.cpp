@@ -67,6 +67,7 @@ struct ctc_tc_plan {
     std::mutex mu;
     std::map<int, DeviceTables> tables;  // by device ordinal
     std::unique_ptr<ctc_tc_plan> packed;  // GEMM on packed [batch,M,K] x [batch,K,N] operands (TTGT)
+    std::mutex transposes_mu;             // one execution through the internal transpose workspace at a time
 };
 
 namespace {
@@ -461,6 +462,41 @@ int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B
                    void *stream)
 {
     if (!plan || !A || !B || !C) return fail(CTC_TC_EINVAL, "null argument");
+    static const bool no_auto = getenv("CTC_TC_NO_AUTO_TTGT") != nullptr;
+    if (plan->plan.prefer_transposes && beta == 0.0 && !no_auto) {
+        // Pathological strides (see Plan::prefer_transposes): transpose A and B, packed GEMM, transpose
+        // into C, through a workspace the plan owns on this device.  Executions of one plan are
+        // serialised on the host here and ordered on the device through the workspace's event.
+        int device = 0;
+        int rc = current_device(device);
+        if (rc) return rc;
+        DeviceTables t;
+        rc = upload_tables(plan, device, t);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> serial(plan->transposes_mu);
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const int64_t bytes = ctc_tc_ttgt_workspace_bytes(plan);
+        void *ws = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(plan->mu);
+            DeviceTables &dt = plan->tables[device];
+            if (dt.ws_used && dt.ws_stream != s) {
+                hipError_t e = hipStreamWaitEvent(s, dt.ws_done, 0);
+                if (e != hipSuccess) return fail_hip(e, "hipStreamWaitEvent");
+            }
+            rc = grow_workspace(dt, (size_t)bytes);
+            if (rc) return rc;
+            ws = dt.ws;
+        }
+        rc = ctc_tc_execute_ttgt(plan, alpha, A, B, 0.0, C, ws, bytes, stream);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lock(plan->mu);
+        DeviceTables &dt = plan->tables[device];
+        (void)hipEventRecord(dt.ws_done, s);
+        dt.ws_stream = s;
+        dt.ws_used = true;
+        return CTC_TC_OK;
+    }
     return launch_plan(plan, alpha, A, B, beta, C, static_cast<hipStream_t>(stream));
 }
 

@@ -65,6 +65,9 @@ struct Plan {
     // into x (contiguous in B), y (contiguous in C) and o (the rest) with one offset
     // table per operand, exactly as in a mode permutation.
     int kernel = 0;  // KernelKind
+    // The fused kernel would read all three tensors element by element at a stride (a batch mode is their
+    // unit-stride mode): ctc_tc_execute transposes the operands explicitly instead (packed operands, beta == 0).
+    bool prefer_transposes = false;
     int64_t sk_X = 1, sk_Y = 1, sk_O = 1;
     std::vector<int64_t> sk_bx, sk_cx, sk_by, sk_cy, sk_bo, sk_co;
 

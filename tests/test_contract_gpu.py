@@ -331,3 +331,32 @@ def test_schedule_does_not_depend_on_earlier_plans(cuda):
         slots_big = s["whole_tiles"]  # one full round
         assert s["tail_tiles"] == 625 - slots_big and s["tail_tiles"] > 0 and s["split"] >= 2, (dt, s, s_small)
         assert slots_big % 256 == 0 and slots_big <= 512, (dt, s)   # two workgroups per CU at most for this tile
+
+
+@pytest.mark.parametrize("spec,ext,dtype", [
+    ("akz,kbz->abz", dict(z=6, a=20, b=24, k=10), "f64"),
+    ("akz,kbz->abz", dict(z=16, a=130, b=72, k=40), "f32"),
+    ("kaz,bzk->baz", dict(z=5, a=33, b=17, k=21), "f64"),       # z fastest in A and C only: fused path
+    ("akyz,kbyz->abyz", dict(y=3, z=4, a=9, b=11, k=7), "f64"),  # two batch modes, both fastest
+])
+def test_batch_fastest_layouts_take_the_transposes(cuda, oracle, spec, ext, dtype):
+    """A batch mode that is the unit-stride mode of A, B and C: ctc_tc_execute transposes explicitly
+    through a workspace the plan owns (beta == 0) and falls back to the fused kernel for beta != 0;
+    both must match the oracle, repeatedly and on two streams."""
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, dtype, cuda)
+    plan = ctc_amd.Plan(spec, ext, dtype)
+    want = oracle.contract(spec, ext, A, B, alpha=1.5, dtype=CODE[dtype])
+    s2 = torch.cuda.Stream()
+    for rep in range(3):
+        dC = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+        if rep == 2:
+            with torch.cuda.stream(s2):
+                plan.execute(dA, dB, dC, alpha=1.5, stream=s2.cuda_stream)
+            s2.synchronize()
+        else:
+            plan.execute(dA, dB, dC, alpha=1.5)
+        _check(dC.cpu().numpy(), want, dtype)
+    C0 = oracle.fill(n_out, 77, CODE[dtype])
+    dC = torch.from_numpy(C0.copy()).to(cuda)
+    plan.execute(dA, dB, dC, alpha=1.5, beta=-0.5)
+    _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=1.5, beta=-0.5, dtype=CODE[dtype]), dtype)
