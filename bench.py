@@ -52,6 +52,37 @@ def cpu_baseline(extent, threads):
     return 2.0 * n ** 6 / dt * 1e-12, dt, float(np.abs(C).max())
 
 
+def cpu_threads():
+    """Host threads the CPU baseline runs on: the process's CPU share (its affinity mask, capped by
+    OMP_NUM_THREADS when the environment sets one: on a shared GPU host os.cpu_count() counts the whole
+    machine, not this job's share)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cap = os.environ.get("OMP_NUM_THREADS", "")
+    return max(1, min(avail, int(cap))) if cap.isdigit() and int(cap) > 0 else avail
+
+
+def verify_slabs(dC, n, first_a, a_idx, b_list):
+    """C[a, b, :, :] of the timed contraction recomputed by the CPU oracle from regenerated operands,
+    for one a (index within this rank's slab; first_a = the slab's first global a) and a few b.
+    Returns the largest |difference| / max |reference| (the parity bar is 1e-12 for fp64)."""
+    from oracle import ref
+    import numpy as np
+    # A[a_idx] is n^3 consecutive elements of the synthetic stream; B is needed whole
+    A1 = ref.fill(n ** 3, SEED_A + (first_a + a_idx) * n ** 3)
+    B = ref.fill(n ** 4, SEED_B).reshape(n, n, n, n)
+    got_all = dC.reshape(-1, n, n, n)[a_idx].cpu().numpy()
+    worst = 0.0
+    for b in b_list:
+        want = ref.contract(SPEC, dict(a=1, b=1, i=n, j=n, e=n, m=n), A1,
+                            np.ascontiguousarray(B[:, b:b + 1]).reshape(-1))
+        err = float(np.abs(got_all[b].reshape(-1) - want).max() / np.abs(want).max())
+        worst = max(worst, err)
+    return worst
+
+
 def measured_traffic(extent, kernel_summary):
     """HBM-side bytes per launch from the committed counter passes (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE, one pass each, tools/pmc_traffic.sh); None when they do not cover this run."""
@@ -140,6 +171,7 @@ def main():
     ap.add_argument("--extent", type=int, default=96, help="extent of every mode (64..96 in BASELINE)")
     ap.add_argument("--cpu-extent", type=int, default=96, help="extent of the CPU-oracle sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the check of the result against the CPU oracle")
     ap.add_argument("--shard", choices=("free", "contracted"), default="free")
     ap.add_argument("--prewarm", type=float, default=0.1, help="seconds of untimed load before the warm-up steps")
     args = ap.parse_args()
@@ -207,6 +239,16 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = flops_job / (elapsed / args.steps) * 1e-12
 
+    # Outside the timed region: the result the timed launches left in C, checked against the CPU oracle
+    # on C[a, b, :, :] for one a of this rank's slab and three b (fp64 bar: 1e-12 of max |C|).
+    rel_err = None
+    if not args.no_verify:
+        rel_err = verify_slabs(C, n, rank * n, n // 3, (0, n // 2, n - 1))
+        if world > 1:
+            t = torch.tensor([rel_err], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rel_err = float(t[0])
+
     if rank == 0:
         s = plan.summary()
         achieved = flops_rank / (kernel_ms * 1e-3) * 1e-12
@@ -245,13 +287,20 @@ def main():
                 "algorithmic_flops_per_launch": flops_rank,
             },
         }
+        if rel_err is not None:
+            out["verified"] = bool(rel_err <= 1e-12)
+            out["verify"] = {"max_rel_err": rel_err, "tolerance": 1e-12,
+                             "what": "C[a,b,:,:] for a=%d, b in (0,%d,%d) of every rank's result vs the CPU oracle, "
+                                     "after the timed launches" % (n // 3, n // 2, n - 1)}
         if not args.no_cpu and world == 1:
-            threads = min(16, os.cpu_count() or 1)
+            threads = cpu_threads()
             tf, dt, _ = cpu_baseline(args.cpu_extent, threads)
             out["cpu_baseline"] = {
-                "value": round(tf, 5), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+                "value": round(tf, 5), "unit": "TFLOP/s", "cores": threads, "threads": threads,
+                "host_logical_cpus": os.cpu_count(), "kind": "port",
                 "sample": "same contraction at all extents %d (2*%d^6 flops, %.1f s) on the build's own CPU "
-                          "oracle; the reference has no CPU contraction path" % (args.cpu_extent, args.cpu_extent, dt),
+                          "oracle (OpenMP over the outermost free index, every CPU of this job's share); the "
+                          "reference has no CPU contraction path" % (args.cpu_extent, args.cpu_extent, dt),
             }
         print(json.dumps(out))
     if world > 1:

@@ -6,15 +6,19 @@
 
 #include <cstdio>
 #include <cstring>
+#include <list>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
 
+#include "api_internal.hpp"
 #include "kernels.hpp"
 #include "permute_plan.hpp"
 #include "planner.hpp"
+
+using ctc_internal::DeviceTables;
 
 namespace {
 
@@ -36,24 +40,10 @@ int fail_hip(hipError_t e, const char *what)
 namespace ctc_internal {
 // shared with the other translation units of the library
 int set_last_error(int code, const std::string &msg) { return fail(code, msg); }
+int set_last_hip_error(hipError_t e, const char *what) { return fail_hip(e, what); }
 }  // namespace ctc_internal
 
 namespace {
-
-// offset tables of one plan resident on one device
-struct DeviceTables {
-    int64_t *base = nullptr;
-    const int64_t *row_a = nullptr, *k_a = nullptr, *k_b = nullptr, *col_b = nullptr;
-    const int64_t *row_c = nullptr, *col_c = nullptr, *bat_a = nullptr, *bat_b = nullptr, *bat_c = nullptr;
-    const int64_t *sk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // bx cx by cy bo co
-    // split-K workspace of this plan on this device: grows on demand; executions on different
-    // streams are ordered through ws_done so that they never share it concurrently
-    void *ws = nullptr;
-    size_t ws_bytes = 0;
-    hipEvent_t ws_done = nullptr;
-    hipStream_t ws_stream = nullptr;
-    bool ws_used = false;
-};
 
 struct PermuteTables {
     int64_t *base = nullptr;
@@ -62,24 +52,18 @@ struct PermuteTables {
 
 }  // namespace
 
-struct ctc_tc_plan {
-    ctc::Plan plan;
-    std::mutex mu;
-    std::map<int, DeviceTables> tables;  // by device ordinal
-    std::unique_ptr<ctc_tc_plan> packed;  // GEMM on packed [batch,M,K] x [batch,K,N] operands (TTGT)
-    std::mutex transposes_mu;             // one execution through the internal transpose workspace at a time
-};
-
 namespace {
 
-int upload_tables(ctc_tc_plan *pl, int device, DeviceTables &out)
+int upload_tables(ctc_tc_plan *pl, int device, DeviceTables &out, bool no_alloc = false)
 {
     std::lock_guard<std::mutex> lock(pl->mu);
     auto it = pl->tables.find(device);
-    if (it != pl->tables.end()) {
+    if (it != pl->tables.end() && it->second.base) {
         out = it->second;
         return CTC_TC_OK;
     }
+    if (no_alloc)
+        return fail(CTC_TC_EINVAL, "the plan's tables are not resident on this device: call ctc_tc_plan_prepare first");
     const ctc::Plan &p = pl->plan;
     // k tables padded for the kernel's look-ahead (see kKTablePad)
     // Pad entry K+j repeats entry K-P+(j mod P), P = elements per 16-byte vector, so
@@ -129,8 +113,29 @@ int upload_tables(ctc_tc_plan *pl, int device, DeviceTables &out)
     return CTC_TC_OK;
 }
 
+void release_tables(std::map<int, DeviceTables> &tables)
+{
+    for (auto &kv : tables) {
+        if (kv.second.base) (void)hipFree(kv.second.base);
+        if (kv.second.ws) (void)hipFree(kv.second.ws);
+        for (void *old : kv.second.retired) (void)hipFree(old);
+        if (kv.second.ws_done) (void)hipEventDestroy(kv.second.ws_done);
+    }
+    tables.clear();
+}
+
+// Offset tables of mode permutations, cached per (device, extents, permutation) and bounded: beyond
+// kPermCacheMax entries the least recently used one is freed (hipFree waits for the device, so a
+// kernel that still reads the evicted tables finishes first; a caller cycling through more shapes
+// than that pays this wait, everyone else never reaches it).
+constexpr size_t kPermCacheMax = 128;
+struct PermCacheEntry {
+    PermuteTables tables;
+    std::list<std::string>::iterator lru;
+};
 std::mutex g_perm_mu;
-std::map<std::string, PermuteTables> g_perm_cache;  // key: device|elem|extents|perm
+std::map<std::string, PermCacheEntry> g_perm_cache;  // key: device|extents|perm
+std::list<std::string> g_perm_lru;                   // most recently used first
 
 int get_permute_tables(int device, int rank, const int64_t *extents, const int *perm, PermuteTables &out)
 {
@@ -141,8 +146,15 @@ int get_permute_tables(int device, int rank, const int64_t *extents, const int *
     std::lock_guard<std::mutex> lock(g_perm_mu);
     auto it = g_perm_cache.find(key);
     if (it != g_perm_cache.end()) {
-        out = it->second;
+        g_perm_lru.splice(g_perm_lru.begin(), g_perm_lru, it->second.lru);
+        out = it->second.tables;
         return CTC_TC_OK;
+    }
+    while (g_perm_cache.size() >= kPermCacheMax) {
+        auto victim = g_perm_cache.find(g_perm_lru.back());
+        (void)hipFree(victim->second.tables.base);
+        g_perm_cache.erase(victim);
+        g_perm_lru.pop_back();
     }
     ctc::PermutePlan pp;
     std::string e = ctc::plan_permute(rank, extents, perm, pp);
@@ -181,7 +193,8 @@ int get_permute_tables(int device, int rank, const int64_t *extents, const int *
         const int64_t v = 8 >> i;  // elements per 16 bytes for 2-, 4-, 8-byte elements
         t.params.vec_ok[i] = (pp.fast_in_extent % v == 0 && pp.fast_out_extent % v == 0) ? 1 : 0;
     }
-    g_perm_cache[key] = t;
+    g_perm_lru.push_front(key);
+    g_perm_cache[key] = PermCacheEntry{t, g_perm_lru.begin()};
     out = t;
     return CTC_TC_OK;
 }
@@ -201,18 +214,16 @@ template <typename V> int64_t copy_out(const V &v, int64_t *out, int64_t cap)
     return n;
 }
 
-// caller holds the plan's mutex
+// Caller holds the plan's mutex.  A workspace that has to grow is replaced, not freed: kernels in
+// flight may still use the old one, and an execution call must not wait for the device.
 int grow_workspace(DeviceTables &dt, size_t bytes)
 {
     if (dt.ws_bytes < bytes) {
-        if (dt.ws) {
-            (void)hipDeviceSynchronize();  // nobody may still be using the old workspace
-            (void)hipFree(dt.ws);
-            dt.ws = nullptr;
-            dt.ws_bytes = 0;
-        }
-        hipError_t e = hipMalloc(&dt.ws, bytes);
-        if (e != hipSuccess) return fail_hip(e, "hipMalloc(split-K workspace)");
+        void *fresh = nullptr;
+        hipError_t e = hipMalloc(&fresh, bytes);
+        if (e != hipSuccess) return fail_hip(e, "hipMalloc(workspace)");
+        if (dt.ws) dt.retired.push_back(dt.ws);
+        dt.ws = fresh;
         dt.ws_bytes = bytes;
     }
     if (!dt.ws_done) {
@@ -222,26 +233,54 @@ int grow_workspace(DeviceTables &dt, size_t bytes)
     return CTC_TC_OK;
 }
 
+// batch entries one launch covers: the batch index is a grid dimension
+constexpr int64_t kMaxBatchPerLaunch = 65535;
+
+// The split-K workspace a tiled-GEMM plan can ask for on the current device: the largest over the
+// layout variants an execution may fall back to (unaligned operand bases take element loads).
+size_t worst_splitk_bytes(const ctc::Plan &p)
+{
+    if (p.kernel != ctc::kKernelGemm) return 0;
+    ctc::GemmParams g;
+    g.M = p.M; g.N = p.N; g.K = p.K;
+    g.batch = (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch);
+    size_t worst = 0;
+    for (int va = 0; va < 2; ++va)
+        for (int vb = 0; vb < 2; ++vb) {
+            const int la = va ? ctc::kLayoutScalar : p.layout_a, lb = vb ? ctc::kLayoutScalar : p.layout_b;
+            ctc::GemmSchedule sch;
+            if (ctc::schedule_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, &sch) == hipSuccess && sch.ws_bytes > worst)
+                worst = sch.ws_bytes;
+        }
+    return worst;
+}
+
+}  // namespace
+
+namespace ctc_internal {
+
 int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, double beta, void *C,
-                hipStream_t stream)
+                hipStream_t stream, const Workspace *fixed_ws, bool no_alloc)
 {
     const ctc::Plan &p = pl->plan;
     int device = 0;
     int rc = current_device(device);
     if (rc) return rc;
     DeviceTables t;
-    rc = upload_tables(pl, device, t);
+    rc = upload_tables(pl, device, t, no_alloc);
     if (rc) return rc;
 
-    if (p.batch > 65535) return fail(CTC_TC_EUNSUPPORTED, "more than 65535 batch entries");
+    // more batch entries than one grid holds: one launch per slab of the batch tables
+    for (int64_t b0 = 0; b0 < p.batch; b0 += kMaxBatchPerLaunch) {
+    const int nb = (int)(p.batch - b0 < kMaxBatchPerLaunch ? p.batch - b0 : kMaxBatchPerLaunch);
     const void *ga = p.swapped ? B : A, *gb = p.swapped ? A : B;
     if (p.kernel != ctc::kKernelGemm &&
         ((reinterpret_cast<uintptr_t>(gb) | reinterpret_cast<uintptr_t>(C)) & 15) == 0) {
         ctc::SkinnyParams s;
         s.A = ga; s.B = gb; s.C = C;
         s.row_a = t.row_a; s.k_a = t.k_a; s.k_b = t.k_b; s.row_c = t.row_c;
-        s.bat_a = t.bat_a; s.bat_b = t.bat_b; s.bat_c = t.bat_c;
-        s.M = (int)p.M; s.K = (int)p.K; s.batch = (int)p.batch;
+        s.bat_a = t.bat_a + b0; s.bat_b = t.bat_b + b0; s.bat_c = t.bat_c + b0;
+        s.M = (int)p.M; s.K = (int)p.K; s.batch = nb;
         s.alpha = alpha; s.beta = beta;
         if (p.kernel == ctc::kKernelSkinnyTranspose) {
             s.transpose = 1;
@@ -254,18 +293,18 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
         }
         hipError_t e = ctc::launch_skinny(p.dtype, s, stream);
         if (e != hipSuccess) return fail_hip(e, "skinny contraction kernel launch");
-        return CTC_TC_OK;
+        continue;
     }
 
     ctc::GemmParams g;
-    g.A = p.swapped ? B : A;
-    g.B = p.swapped ? A : B;
+    g.A = ga;
+    g.B = gb;
     g.C = C;
     g.row_a = t.row_a; g.k_a = t.k_a; g.k_b = t.k_b; g.col_b = t.col_b;
     g.row_c = t.row_c; g.col_c = t.col_c;
-    g.bat_a = t.bat_a; g.bat_b = t.bat_b; g.bat_c = t.bat_c;
+    g.bat_a = t.bat_a + b0; g.bat_b = t.bat_b + b0; g.bat_c = t.bat_c + b0;
     g.M = p.M; g.N = p.N; g.K = p.K;
-    g.batch = (int)p.batch;
+    g.batch = nb;
     g.alpha = alpha; g.beta = beta;
     g.group = p.tile.group;
     // 16-byte stores of C need an aligned base as well
@@ -281,7 +320,16 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     ctc::GemmSchedule sch;
     hipError_t e = ctc::schedule_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, &sch);
     if (e != hipSuccess) return fail_hip(e, "contraction schedule");
-    void *ws = nullptr;
+    if (sch.ws_bytes > 0 && fixed_ws) {
+        // caller-provided workspace: nothing is allocated, nothing is ordered (the caller's business)
+        if (sch.ws_bytes > fixed_ws->fixed_bytes)
+            return fail(CTC_TC_EUNSUPPORTED, "this contraction needs " + std::to_string(sch.ws_bytes) +
+                                                 " bytes of split-K scratch, the fixed scratch buffer holds " +
+                                                 std::to_string(fixed_ws->fixed_bytes));
+        e = ctc::launch_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, sch, fixed_ws->fixed, stream);
+        if (e != hipSuccess) return fail_hip(e, "contraction kernel launch");
+        continue;
+    }
     if (sch.ws_bytes > 0) {
         std::lock_guard<std::mutex> lock(pl->mu);
         DeviceTables &dt = pl->tables[device];
@@ -291,17 +339,68 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
         }
         int wrc = grow_workspace(dt, sch.ws_bytes);
         if (wrc) return wrc;
-        ws = dt.ws;
-        e = ctc::launch_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, sch, ws, stream);
+        e = ctc::launch_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, sch, dt.ws, stream);
         if (e != hipSuccess) return fail_hip(e, "contraction kernel launch");
         (void)hipEventRecord(dt.ws_done, stream);
         dt.ws_stream = stream;
         dt.ws_used = true;
-        return CTC_TC_OK;
+        continue;
     }
     e = ctc::launch_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, sch, nullptr, stream);
     if (e != hipSuccess) return fail_hip(e, "contraction kernel launch");
+    }
     return CTC_TC_OK;
+}
+
+}  // namespace ctc_internal
+
+using ctc_internal::launch_plan;
+
+namespace {
+
+// same contraction on operands already in [batch,M,K] / [batch,K,N] / [batch,M,N] order
+int ensure_packed_plan(ctc_tc_plan *plan)
+{
+    const ctc::Plan &p = plan->plan;
+    std::lock_guard<std::mutex> lock(plan->mu);
+    if (plan->packed) return CTC_TC_OK;
+    std::string sa, sb, sc, names;
+    std::vector<int64_t> ext;
+    auto add = [&](std::string &s, const std::vector<int> &ids) {
+        for (int id : ids) s.push_back(p.modes[id].name);
+    };
+    add(sa, p.canon_batch); add(sa, p.canon_m); add(sa, p.canon_k);
+    add(sb, p.canon_batch); add(sb, p.canon_k); add(sb, p.canon_n);
+    add(sc, p.canon_batch); add(sc, p.canon_m); add(sc, p.canon_n);
+    for (auto &m : p.modes) { names.push_back(m.name); ext.push_back(m.extent); }
+    std::unique_ptr<ctc_tc_plan> q(new ctc_tc_plan());
+    std::string e = ctc::build_plan(sa + "," + sb + "->" + sc, (int)names.size(), names.data(),
+                                    ext.data(), nullptr, nullptr, nullptr, p.dtype, q->plan);
+    if (!e.empty()) return fail(CTC_TC_EINVAL, e);
+    plan->packed = std::move(q);
+    return CTC_TC_OK;
+}
+
+// extents of the three explicit transposes: A as given, B as given, [batch,M,N] in GEMM order
+struct TransposeShapes {
+    std::vector<int64_t> ea, eb, eg;
+};
+TransposeShapes transpose_shapes(const ctc::Plan &p)
+{
+    auto ext_of = [&](const std::vector<int> &ids) {
+        std::vector<int64_t> e;
+        for (int id : ids) e.push_back(p.modes[id].extent);
+        return e;
+    };
+    TransposeShapes t;
+    t.ea = ext_of(p.a_modes);
+    t.eb = ext_of(p.b_modes);
+    std::vector<int> gemm_order;
+    gemm_order.insert(gemm_order.end(), p.canon_batch.begin(), p.canon_batch.end());
+    gemm_order.insert(gemm_order.end(), p.canon_m.begin(), p.canon_m.end());
+    gemm_order.insert(gemm_order.end(), p.canon_n.begin(), p.canon_n.end());
+    t.eg = ext_of(gemm_order);
+    return t;
 }
 
 }  // namespace
@@ -337,15 +436,8 @@ int ctc_tc_plan_create(const char *spec, int n_ext, const char *mode_names, cons
 int ctc_tc_plan_destroy(ctc_tc_plan *plan)
 {
     if (!plan) return CTC_TC_OK;
-    auto release = [](std::map<int, DeviceTables> &tables) {
-        for (auto &kv : tables) {
-            if (kv.second.base) (void)hipFree(kv.second.base);
-            if (kv.second.ws) (void)hipFree(kv.second.ws);
-            if (kv.second.ws_done) (void)hipEventDestroy(kv.second.ws_done);
-        }
-    };
-    release(plan->tables);
-    if (plan->packed) release(plan->packed->tables);
+    release_tables(plan->tables);
+    if (plan->packed) release_tables(plan->packed->tables);
     delete plan;
     return CTC_TC_OK;
 }
@@ -406,7 +498,7 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
         if (rc) return rc;
         ctc::GemmParams g;
         g.M = p.M; g.N = p.N; g.K = p.K;
-        g.batch = (int)p.batch;
+        g.batch = (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch);
         ctc::GemmSchedule sch;
         hipError_t e = ctc::schedule_gemm(p.dtype, p.layout_a, p.layout_b, p.tile.bm, p.tile.bn, g, &sch);
         if (e != hipSuccess) return fail_hip(e, "contraction schedule");
@@ -443,17 +535,26 @@ int ctc_tc_plan_prepare(ctc_tc_plan *plan)
     rc = upload_tables(plan, device, t);
     if (rc) return rc;
     const ctc::Plan &p = plan->plan;
-    if (p.kernel == ctc::kKernelGemm && p.batch <= 65535) {
-        // the split-K workspace the vector-load variant will ask for
-        ctc::GemmParams g;
-        g.M = p.M; g.N = p.N; g.K = p.K;
-        g.batch = (int)p.batch;
-        ctc::GemmSchedule sch;
-        if (ctc::schedule_gemm(p.dtype, p.layout_a, p.layout_b, p.tile.bm, p.tile.bn, g, &sch) == hipSuccess &&
-            sch.ws_bytes > 0) {
-            std::lock_guard<std::mutex> lock(plan->mu);
-            rc = grow_workspace(plan->tables[device], sch.ws_bytes);
-        }
+    size_t bytes = worst_splitk_bytes(p);
+    if (p.prefer_transposes) {
+        // everything the explicit-transpose execution touches: the packed plan with its own tables and
+        // split-K workspace, the three permutations' tables, the workspace of the three packed tensors
+        rc = ensure_packed_plan(plan);
+        if (rc) return rc;
+        rc = ctc_tc_plan_prepare(plan->packed.get());
+        if (rc) return rc;
+        TransposeShapes ts = transpose_shapes(p);
+        PermuteTables unused;
+        rc = get_permute_tables(device, (int)ts.ea.size(), ts.ea.data(), p.perm_a.data(), unused);
+        if (rc == CTC_TC_OK) rc = get_permute_tables(device, (int)ts.eb.size(), ts.eb.data(), p.perm_b.data(), unused);
+        if (rc == CTC_TC_OK) rc = get_permute_tables(device, (int)ts.eg.size(), ts.eg.data(), p.perm_c.data(), unused);
+        if (rc) return rc;
+        const size_t ttgt = (size_t)ctc_tc_ttgt_workspace_bytes(plan);
+        if (ttgt > bytes) bytes = ttgt;
+    }
+    if (bytes > 0) {
+        std::lock_guard<std::mutex> lock(plan->mu);
+        rc = grow_workspace(plan->tables[device], bytes);
     }
     return rc;
 }
@@ -557,45 +658,17 @@ int ctc_tc_execute_ttgt(ctc_tc_plan *plan, double alpha, const void *A, const vo
     char *wb = wa + pad(p.size_a * es);
     char *wc = wb + pad(p.size_b * es);
 
-    {
-        std::lock_guard<std::mutex> lock(plan->mu);
-        if (!plan->packed) {
-            // same contraction on operands already in [batch,M,K] / [batch,K,N] / [batch,M,N] order
-            std::string sa, sb, sc, names;
-            std::vector<int64_t> ext;
-            auto add = [&](std::string &s, const std::vector<int> &ids) {
-                for (int id : ids) s.push_back(p.modes[id].name);
-            };
-            add(sa, p.canon_batch); add(sa, p.canon_m); add(sa, p.canon_k);
-            add(sb, p.canon_batch); add(sb, p.canon_k); add(sb, p.canon_n);
-            add(sc, p.canon_batch); add(sc, p.canon_m); add(sc, p.canon_n);
-            for (auto &m : p.modes) { names.push_back(m.name); ext.push_back(m.extent); }
-            std::unique_ptr<ctc_tc_plan> q(new ctc_tc_plan());
-            std::string e = ctc::build_plan(sa + "," + sb + "->" + sc, (int)names.size(), names.data(),
-                                            ext.data(), nullptr, nullptr, nullptr, p.dtype, q->plan);
-            if (!e.empty()) return fail(CTC_TC_EINVAL, e);
-            plan->packed = std::move(q);
-        }
-    }
-    auto ext_of = [&](const std::vector<int> &ids) {
-        std::vector<int64_t> e;
-        for (int id : ids) e.push_back(p.modes[id].extent);
-        return e;
-    };
-    std::vector<int64_t> ea = ext_of(p.a_modes), eb = ext_of(p.b_modes);
-    int rc = ctc_tc_permute(A, wa, (int)ea.size(), ea.data(), p.perm_a.data(), es, stream);
+    int rc = ensure_packed_plan(plan);
     if (rc) return rc;
-    rc = ctc_tc_permute(B, wb, (int)eb.size(), eb.data(), p.perm_b.data(), es, stream);
+    TransposeShapes ts = transpose_shapes(p);
+    rc = ctc_tc_permute(A, wa, (int)ts.ea.size(), ts.ea.data(), p.perm_a.data(), es, stream);
+    if (rc) return rc;
+    rc = ctc_tc_permute(B, wb, (int)ts.eb.size(), ts.eb.data(), p.perm_b.data(), es, stream);
     if (rc) return rc;
     rc = launch_plan(plan->packed.get(), alpha, wa, wb, 0.0, wc, static_cast<hipStream_t>(stream));
     if (rc) return rc;
     // [batch,M,N] -> C
-    std::vector<int> gemm_order;
-    gemm_order.insert(gemm_order.end(), p.canon_batch.begin(), p.canon_batch.end());
-    gemm_order.insert(gemm_order.end(), p.canon_m.begin(), p.canon_m.end());
-    gemm_order.insert(gemm_order.end(), p.canon_n.begin(), p.canon_n.end());
-    std::vector<int64_t> eg = ext_of(gemm_order);
-    return ctc_tc_permute(wc, C, (int)eg.size(), eg.data(), p.perm_c.data(), es, stream);
+    return ctc_tc_permute(wc, C, (int)ts.eg.size(), ts.eg.data(), p.perm_c.data(), es, stream);
 }
 
 int ctc_tc_grouped_contract(const ctc_tc_small_gemm *problems, int count, int dtype, double alpha, const void *A,

@@ -20,12 +20,21 @@ int set_last_error(int code, const std::string &msg);  // api.cpp
 
 namespace {
 
-// per-device staging for work tables: a pinned host ring and a device buffer that only grow
-struct Staging {
+// Per-device staging for work tables: a small ring of (pinned host buffer, device buffer) pairs that
+// only grow.  A slot's `done` event is recorded BEHIND the scoring kernel that reads the slot's device
+// table, and the host waits on it before the slot is filled again, so calls on different streams (or
+// host threads) never share a table that a kernel in flight still reads; up to kSlots calls per device
+// are in flight before a call has to wait.
+struct Slot {
     ctc::FastrWork *host = nullptr;
     ctc::FastrWork *dev = nullptr;
     size_t capacity = 0;
-    hipEvent_t done = nullptr;  // last upload that read `host`
+    hipEvent_t done = nullptr;  // the last kernel that read `dev`
+};
+constexpr int kSlots = 4;
+struct Staging {
+    Slot slot[kSlots];
+    unsigned next = 0;
 };
 std::mutex g_mu;
 std::map<int, Staging> g_staging;
@@ -81,8 +90,10 @@ extern "C" int ctc_fastr_best_offsets(const uint8_t *d_ref, const uint8_t *d_rea
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     std::lock_guard<std::mutex> lock(g_mu);
-    Staging &st = g_staging[device];
-    if (st.done) (void)hipEventSynchronize(st.done);  // the previous upload has consumed the pinned buffer
+    Staging &ring = g_staging[device];
+    Slot &st = ring.slot[ring.next++ % kSlots];
+    // the upload and the kernel that used this slot last have finished with its two buffers
+    if (st.done) (void)hipEventSynchronize(st.done);
     if (st.capacity < work.size()) {
         if (st.host) (void)hipHostFree(st.host);
         if (st.dev) (void)hipFree(st.dev);
@@ -101,7 +112,6 @@ extern "C" int ctc_fastr_best_offsets(const uint8_t *d_ref, const uint8_t *d_rea
     memcpy(st.host, work.data(), work.size() * sizeof(ctc::FastrWork));
     e = hipMemcpyAsync(st.dev, st.host, work.size() * sizeof(ctc::FastrWork), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return set_last_error(CTC_TC_EDEVICE, std::string("work table upload: ") + hipGetErrorString(e));
-    (void)hipEventRecord(st.done, s);
 
     ctc::FastrParams p;
     p.ref = d_ref;
@@ -114,6 +124,7 @@ extern "C" int ctc_fastr_best_offsets(const uint8_t *d_ref, const uint8_t *d_rea
     p.best_index = d_best_index;
     p.read_stride = read_stride;
     e = ctc::launch_fastr(p, (int)work.size(), staged, s);
+    (void)hipEventRecord(st.done, s);  // also after a failed launch: the upload still reads st.host
     if (e != hipSuccess) return set_last_error(CTC_TC_EDEVICE, std::string("scoring kernel launch: ") + hipGetErrorString(e));
     return CTC_TC_OK;
 }

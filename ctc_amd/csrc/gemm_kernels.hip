@@ -522,6 +522,7 @@ template <typename T, int LA, int LB, int BM, int BN>
 hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
 {
     constexpr int BK = tile_bk<T, BM>(), WM = 2, WN = 2;
+    static_assert(3 * BK <= kKTablePad, "the prologue reads the k tables three K-tiles ahead");
     GemmSchedule s;
     s.nbm = (int)((p.M + BM - 1) / BM);
     s.nbn = (int)((p.N + BN - 1) / BN);

@@ -9,8 +9,10 @@ namespace ctc {
 
 // The device copies of k_a and k_b carry this many extra entries (repeating the last
 // whole 16-byte vector's entries) so that the kernel's look-ahead reads past K need
-// no clamping and stay inside the operand.
-constexpr int kKTablePad = 64;
+// no clamping and stay inside the operand.  The furthest look-ahead is the prologue's third
+// K-tile (entries up to 3 * BK - 1 whatever K is), with BK <= 32 for f64/f32 and one tile of 64
+// for bf16.
+constexpr int kKTablePad = 128;
 
 // One GEMM-shaped contraction.  All tables hold ELEMENT offsets:
 //   A(m,k) = A[bat_a[b] + row_a[m] + k_a[k]],  B(k,n) = B[bat_b[b] + k_b[k] + col_b[n]],

@@ -156,8 +156,14 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
 int ctc_tc_plan_shard(const ctc_tc_plan *plan, char mode, int rank, int nranks,
                       ctc_tc_plan **shard, int64_t *off_a, int64_t *off_b, int64_t *off_c);
 
-/* Upload the plan's offset tables to the current device ahead of time, so that
- * ctc_tc_execute allocates nothing later.  Optional. */
+/* Set-up of a plan on the current device, ahead of the first execution: uploads the offset
+ * tables, allocates the workspace the plan's executions will use (split-K partial sums for every
+ * layout variant an execution may fall back to; for a plan that runs through explicit transposes
+ * also the packed sub-plan, the permutation tables and the three packed tensors).  After it,
+ * ctc_tc_execute on this device allocates nothing and never waits for the device.  Optional
+ * (ctc_tc_execute does the same on first use).
+ * No reference counterpart; the nearest thing is the once-per-run OpenCL set-up in
+ * apps/fastr/IndelRealigner.cpp:1219-1232. */
 int ctc_tc_plan_prepare(ctc_tc_plan *plan);
 
 /*

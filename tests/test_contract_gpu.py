@@ -360,3 +360,33 @@ def test_batch_fastest_layouts_take_the_transposes(cuda, oracle, spec, ext, dtyp
     dC = torch.from_numpy(C0.copy()).to(cuda)
     plan.execute(dA, dB, dC, alpha=1.5, beta=-0.5)
     _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=1.5, beta=-0.5, dtype=CODE[dtype]), dtype)
+
+
+@pytest.mark.parametrize("spec,ext", [
+    ("zak,zkb->zab", dict(z=70000, a=5, b=6, k=4)),        # tiled kernel, batch slowest
+    ("zkn,zmk->zmn", dict(z=66000, m=2, n=4096, k=3)),     # skinny kernel
+])
+def test_more_batch_entries_than_one_grid_holds(cuda, oracle, spec, ext):
+    """The batch index is a grid dimension (65535 at most): larger batches run as several launches."""
+    dtype = "f32"
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, dtype, cuda)
+    dC = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+    plan = ctc_amd.Plan(spec, ext, dtype)
+    plan.prepare()
+    plan.execute(dA, dB, dC)
+    _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE[dtype]), dtype)
+
+
+def test_prepare_covers_the_explicit_transpose_path(cuda, oracle):
+    """After prepare(), executing a plan that runs through explicit transposes takes no device memory."""
+    spec, ext = "akz,kbz->abz", dict(z=16, a=96, b=80, k=64)
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, "f64", cuda)
+    dC = torch.full((n_out,), float("nan"), dtype=torch.float64, device=cuda)
+    plan = ctc_amd.Plan(spec, ext, "f64")
+    plan.prepare()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    plan.execute(dA, dB, dC)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B), "f64")

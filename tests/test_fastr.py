@@ -193,3 +193,32 @@ def test_gpu_empty_batch(cuda):
     d.run()
     torch.cuda.synchronize()
     assert int(d.best_score[0]) == -7
+
+
+@pytest.mark.gpu
+def test_gpu_batches_on_two_streams_do_not_share_a_work_table(cuda):
+    """Calls on different streams back to back: the second call's work table must not replace the
+    one the first call's kernel is still reading (more calls than the library has staging slots)."""
+    import torch
+    from ctc_amd import fastr
+    kws = [dict(seed=0xFA57), dict(seed=21, n_regions=9, read_len=60, ref_len=(100, 900)),
+           dict(seed=22, n_regions=17, reads=(5, 40), read_len=100, ref_len=(300, 1200)),
+           dict(seed=23, n_regions=3, read_len=80, ref_len=(150, 500)),
+           dict(seed=24, n_regions=12), dict(seed=25, n_regions=2, reads=(60, 90), read_len=100, ref_len=(800, 1200))]
+    batches = [ofastr.make_batch(**kw) for kw in kws]
+    wants = [ofastr.best_offsets(b) for b in batches]
+    devs = [fastr.DeviceBatch(b, cuda) for b in batches]
+    streams = [torch.cuda.Stream(device=cuda) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rounds in range(3):
+        for d in devs:
+            d.best_score.fill_(-1)
+            d.best_index.fill_(-1)
+        torch.cuda.synchronize()
+        for i, d in enumerate(devs):
+            d.run(stream=streams[i % 2])
+        torch.cuda.synchronize()
+        for d, (ws, wi) in zip(devs, wants):
+            score, index = d.results()
+            assert np.array_equal(score, ws)
+            assert np.array_equal(index, wi)
