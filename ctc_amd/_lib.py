@@ -16,7 +16,7 @@ SYMBOLS = (
     "ctc_tc_plan_create", "ctc_tc_plan_destroy", "ctc_tc_plan_describe", "ctc_tc_plan_get",
     "ctc_tc_plan_shard", "ctc_tc_plan_prepare", "ctc_tc_execute", "ctc_tc_permute",
     "ctc_tc_ttgt_workspace_bytes", "ctc_tc_execute_ttgt", "ctc_tc_fill", "ctc_tc_time_execute",
-    "ctc_tc_grouped_contract",
+    "ctc_tc_grouped_contract", "ctc_tc_execute_noalloc", "ctc_tc_noalloc_scratch_bytes",
 )
 # every symbol include/ctc_fastr.h declares
 FASTR_SYMBOLS = ("ctc_fastr_best_offsets", "ctc_fastr_sw_align", "ctc_fastr_sw_workspace_bytes")
@@ -73,6 +73,9 @@ def load():
     L.ctc_tc_plan_prepare.argtypes = [vp]
     L.ctc_tc_execute.restype = ctypes.c_int
     L.ctc_tc_execute.argtypes = [vp, ctypes.c_double, vp, vp, ctypes.c_double, vp, vp]
+    L.ctc_tc_execute_noalloc.restype = ctypes.c_int
+    L.ctc_tc_execute_noalloc.argtypes = [vp, ctypes.c_double, vp, vp, ctypes.c_double, vp, vp]
+    L.ctc_tc_noalloc_scratch_bytes.restype = ctypes.c_int64
     L.ctc_tc_permute.restype = ctypes.c_int
     L.ctc_tc_permute.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_int, vp]
     L.ctc_tc_ttgt_workspace_bytes.restype = ctypes.c_int64

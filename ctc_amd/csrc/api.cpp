@@ -358,6 +358,31 @@ using ctc_internal::launch_plan;
 
 namespace {
 
+// ---- fixed scratch of ctc_tc_execute_noalloc ---------------------------------------------------------
+// One buffer per GPU, part of the library's code object, so the entry point never allocates.  It takes
+// the split-K partial sums (every chunk slab is written in full before the fix-up kernel reads it, so
+// nothing has to be cleared between calls).  `scratch` is a host-side stand-in for the symbol: the
+// device address is looked up once per device (scratch_setup, reached from ctc_tc_plan_prepare) and only
+// that address is ever handed to a kernel.
+constexpr size_t kScratchBytes = size_t(128) << 20;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+void *g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+
+// caller has made `device` current
+int scratch_setup(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return CTC_TC_OK;  // such a device simply has no no-alloc path
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return CTC_TC_OK;
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return fail_hip(e, "hipGetSymbolAddress(scratch)");
+    g_scratch_ptr[device] = ptr;
+    return CTC_TC_OK;
+}
+
 // same contraction on operands already in [batch,M,K] / [batch,K,N] / [batch,M,N] order
 int ensure_packed_plan(ctc_tc_plan *plan)
 {
@@ -531,6 +556,8 @@ int ctc_tc_plan_prepare(ctc_tc_plan *plan)
     int device = 0;
     int rc = current_device(device);
     if (rc) return rc;
+    rc = scratch_setup(device);
+    if (rc) return rc;
     DeviceTables t;
     rc = upload_tables(plan, device, t);
     if (rc) return rc;
@@ -599,6 +626,26 @@ int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B
         return CTC_TC_OK;
     }
     return launch_plan(plan, alpha, A, B, beta, C, static_cast<hipStream_t>(stream));
+}
+
+int64_t ctc_tc_noalloc_scratch_bytes(void) { return (int64_t)kScratchBytes; }
+
+int ctc_tc_execute_noalloc(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta, void *C,
+                           void *stream)
+{
+    if (!plan || !A || !B || !C) return fail(CTC_TC_EINVAL, "null argument");
+    int device = 0;
+    int rc = current_device(device);
+    if (rc) return rc;
+    if (device < 0 || device >= kMaxDevices || g_scratch_ptr[device] == nullptr)
+        return fail(CTC_TC_EINVAL, "ctc_tc_execute_noalloc: call ctc_tc_plan_prepare on this device first "
+                                   "(it resolves the scratch buffer's address and uploads the plan's tables)");
+    // always the fused kernel (a plan that prefers explicit transposes would need three packed tensors
+    // of workspace); split-K partial sums go to this device's fixed scratch buffer
+    ctc_internal::Workspace ws;
+    ws.fixed = g_scratch_ptr[device];
+    ws.fixed_bytes = kScratchBytes;
+    return launch_plan(plan, alpha, A, B, beta, C, static_cast<hipStream_t>(stream), &ws, /*no_alloc=*/true);
 }
 
 int ctc_tc_permute(const void *in, void *out, int rank, const int64_t *extents_in, const int *perm,

@@ -172,6 +172,13 @@ class Plan:
                                        _stream(stream)))
         return C
 
+    def execute_noalloc(self, A, B, C, alpha=1.0, beta=0.0, stream=None):
+        """execute() through the library's fixed per-GPU scratch buffer: no device allocation.  Needs
+        prepare() first; calls that overlap on one GPU race (they share the buffer)."""
+        check(self._lib.ctc_tc_execute_noalloc(self._h, float(alpha), _ptr(A), _ptr(B), float(beta), _ptr(C),
+                                               _stream(stream)))
+        return C
+
     def ttgt_workspace_bytes(self):
         return int(check(self._lib.ctc_tc_ttgt_workspace_bytes(self._h)))
 
@@ -257,6 +264,11 @@ def grouped_contract(problems, A, B, C, alpha=1.0, beta=0.0, stream=None):
     check(L.ctc_tc_grouped_contract(_ptr(problems), count, _dtype_code(A.dtype), float(alpha), _ptr(A), _ptr(B),
                                     float(beta), _ptr(C), _stream(stream)))
     return C
+
+
+def noalloc_scratch_bytes():
+    """Size of the fixed per-GPU scratch buffer Plan.execute_noalloc works in."""
+    return int(_lib.load().ctc_tc_noalloc_scratch_bytes())
 
 
 def device_count():

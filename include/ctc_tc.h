@@ -159,9 +159,10 @@ int ctc_tc_plan_shard(const ctc_tc_plan *plan, char mode, int rank, int nranks,
 /* Set-up of a plan on the current device, ahead of the first execution: uploads the offset
  * tables, allocates the workspace the plan's executions will use (split-K partial sums for every
  * layout variant an execution may fall back to; for a plan that runs through explicit transposes
- * also the packed sub-plan, the permutation tables and the three packed tensors).  After it,
- * ctc_tc_execute on this device allocates nothing and never waits for the device.  Optional
- * (ctc_tc_execute does the same on first use).
+ * also the packed sub-plan, the permutation tables and the three packed tensors) and resolves the
+ * address of this device's fixed scratch buffer (see ctc_tc_execute_noalloc).  After it,
+ * ctc_tc_execute on this device allocates nothing and never waits for the device.  Optional for
+ * ctc_tc_execute (which does the same on first use), required before ctc_tc_execute_noalloc.
  * No reference counterpart; the nearest thing is the once-per-run OpenCL set-up in
  * apps/fastr/IndelRealigner.cpp:1219-1232. */
 int ctc_tc_plan_prepare(ctc_tc_plan *plan);
@@ -173,6 +174,27 @@ int ctc_tc_plan_prepare(ctc_tc_plan *plan);
  */
 int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B,
                    double beta, void *C, void *stream);
+
+/*
+ * ctc_tc_execute for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.
+ * Same arguments and result as ctc_tc_execute, with these differences:
+ *   - it calls no hipMalloc / hipFree and no allocating library routine; the only device memory
+ *     beyond A, B and C it touches is a fixed scratch buffer of ctc_tc_noalloc_scratch_bytes()
+ *     bytes (128 MiB) that is part of the library's code object, one copy per GPU, held until the
+ *     process ends; the split-K partial sums of the last, partly filled round of tiles go there;
+ *   - ctc_tc_plan_prepare must have been called for this plan on the current device (it uploads
+ *     the tables and resolves the scratch buffer's device address); otherwise CTC_TC_EINVAL;
+ *   - a contraction whose schedule needs more scratch than that is rejected with
+ *     CTC_TC_EUNSUPPORTED (ctc_tc_plan_get(CTC_TC_Q_SCHEDULE) reports the bytes a plan needs);
+ *   - every call on one GPU, from any plan, stream or thread, shares that GPU's buffer: calls that
+ *     overlap in time on one GPU race.  Order them (one stream, or events) yourself.  Nothing in
+ *     the buffer has to be cleared between calls: every partial sum is written before it is read;
+ *   - a plan that ctc_tc_execute would run through explicit transposes runs the fused kernel here.
+ */
+int64_t ctc_tc_noalloc_scratch_bytes(void);
+int ctc_tc_execute_noalloc(ctc_tc_plan *plan, double alpha, const void *A, const void *B,
+                           double beta, void *C, void *stream);
 
 /*
  * Mode permutation on the device: out mode p = in mode perm[p]; both packed,

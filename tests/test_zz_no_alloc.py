@@ -1,0 +1,78 @@
+"""ctc_tc_execute_noalloc (the entry point that allocates nothing: split-K partial sums go to the
+library's fixed per-GPU scratch buffer) against ctc_tc_execute, through the C ABI.
+
+Both entry points launch the same kernels with the same schedule, so the results must agree bit
+for bit; ctc_tc_execute itself is checked against the CPU oracle here as well (1e-12 / 1e-5 of
+max |C|).  Two calls in a row, the second on a smaller contraction, with the result buffers
+poisoned in between: stale partial sums of the first call must not reach the second."""
+import numpy as np
+import pytest
+import torch
+
+import ctc_amd
+
+pytestmark = pytest.mark.gpu
+
+SPEC = "aeim,ebmj->abij"
+TOL = {"f64": 1e-12, "f32": 1e-5}
+TDT = {"f64": torch.float64, "f32": torch.float32}
+CODE = {"f64": 0, "f32": 1}
+
+
+def _run_pair(cuda, oracle, n, dtype, check_oracle):
+    ext = dict(a=n, b=n, i=n, j=n, e=n, m=n)
+    A = oracle.fill(n ** 4, 0xC7C0A, CODE[dtype])
+    B = oracle.fill(n ** 4, 0xC7C0B, CODE[dtype])
+    dA, dB = torch.from_numpy(A).to(cuda), torch.from_numpy(B).to(cuda)
+    plan = ctc_amd.Plan(SPEC, ext, dtype)
+    plan.prepare()
+    sched = plan.schedule()
+    # the case must really use scratch: tiles of the last round are cut along K
+    assert sched["workspace_bytes"] > 0, sched
+    assert sched["workspace_bytes"] <= ctc_amd.noalloc_scratch_bytes()
+    want = torch.full((n ** 4,), float("nan"), dtype=TDT[dtype], device=cuda)
+    got = torch.full((n ** 4,), float("nan"), dtype=TDT[dtype], device=cuda)
+    plan.execute(dA, dB, want)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    plan.execute_noalloc(dA, dB, got)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before  # no device memory was taken
+    assert torch.equal(got, want)
+    # beta != 0 reads C back: same comparison with an accumulate
+    plan.execute(dA, dB, want, alpha=0.5, beta=-1.25)
+    plan.execute_noalloc(dA, dB, got, alpha=0.5, beta=-1.25)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    if check_oracle:
+        ref = oracle.contract(SPEC, ext, A, B, dtype=CODE[dtype]).astype(np.float64)
+        ref = 0.5 * ref - 1.25 * ref
+        err = np.abs(got.cpu().numpy().astype(np.float64) - ref).max()
+        assert err <= 2 * TOL[dtype] * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_noalloc_matches_execute_twice_second_smaller(cuda, oracle, dtype):
+    _run_pair(cuda, oracle, 48, dtype, check_oracle=False)  # 2304^3: large tile, last round cut along K
+    _run_pair(cuda, oracle, 24, dtype, check_oracle=True)   # 576^3: fewer tiles than slots, all cut along K
+
+
+def test_noalloc_needs_prepare_and_rejects_oversized_schedules(cuda, oracle):
+    n = 16
+    ext = dict(a=n, b=n, i=n, j=n, e=n, m=n)
+    x = torch.zeros(n ** 4, dtype=torch.float64, device=cuda)
+    plan = ctc_amd.Plan(SPEC, ext, "f64")
+    with pytest.raises(ctc_amd.CtcError, match="ctc_tc_plan_prepare"):
+        plan.execute_noalloc(x, x, x.clone())
+    # 300 tiles of 128 x 128 (fewer than the chip's workgroup slots, so every tile is cut along a long
+    # K): more partial sums than the fixed buffer holds must be refused, not truncated
+    big = ctc_amd.Plan("ak,kb->ab", dict(a=2560, b=1920, k=16384), "f64")
+    big.prepare()
+    need = big.schedule()["workspace_bytes"]
+    assert need > ctc_amd.noalloc_scratch_bytes(), need
+    a = torch.zeros(2560 * 16384, dtype=torch.float64, device=cuda)
+    c = torch.zeros(2560 * 1920, dtype=torch.float64, device=cuda)
+    with pytest.raises(ctc_amd.CtcError, match="scratch"):
+        big.execute_noalloc(a, a, c)
+    big.execute(a, a, c)  # the allocating entry point still runs it
+    torch.cuda.synchronize()
