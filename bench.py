@@ -96,68 +96,117 @@ def measured_traffic(extent, kernel_summary):
     return t["per_launch_bytes"]["total_corrected"]
 
 
-def bench_contracted(args, world, rank, dev, backend):
-    """Contracted index e split over the ranks, partial results summed by one reduce-scatter."""
-    from ctc_amd.sharded import ShardedContraction
-    n = args.extent
+def _barrier(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(values, world, dev, backend):
+    if world == 1:
+        return [float(v) for v in values]
+    t = torch.tensor(list(values), dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t]
+
+
+def run_contracted(n, world, rank, dev, backend, steps, warmup, nchunks=4):
+    """BASELINE configs[3], second variant: abij=aeim,ebmj at all extents n with the CONTRACTED index e
+    split over the ranks.  Every rank holds 1/N of A and of B, the partial results are summed by RCCL
+    reduce-scatters issued from C (ctc_tc_sharded_execute) chunk by chunk behind the GEMMs; afterwards
+    every rank owns |C|/N.  Strong scaling; the step time includes the collectives."""
+    from ctc_amd.sharded import Communicator, ShardedContraction
     ext = dict(a=n, b=n, i=n, j=n, e=n, m=n)
-    sc = ShardedContraction(SPEC, ext, "f64", "e", rank, world)
-    # rank-local packed slabs: A[a, e/p, i, m], B[e/p, b, m, j]; synthetic, one stream per rank
+    sc = ShardedContraction(SPEC, ext, "f64", "e", rank, world, reduce="reduce_scatter", nchunks=nchunks)
     A = torch.empty(sc.local_numel("a"), dtype=torch.float64, device=dev)
     B = torch.empty(sc.local_numel("b"), dtype=torch.float64, device=dev)
     ctc_amd.fill(A, SEED_A + rank * 0x100000000)
     ctc_amd.fill(B, SEED_B + rank * 0x100000000)
-    partial = torch.empty(sc.full_c_numel(), dtype=torch.float64, device=dev)
-    C = torch.empty(sc.full_c_numel() // world, dtype=torch.float64, device=dev)
-    sc.plan.prepare()
-
-    def step():
-        sc.execute(A, B, C, scratch=partial)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # untimed load so the chip holds its clocks: kernel only (a timed loop may not hold a
-    # collective, the ranks would call it different numbers of times)
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm:
-        sc.plan.execute(A, B, partial)
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    barrier()
+    partial = torch.empty(sc.workspace_numel(), dtype=torch.float64, device=dev)
+    C = torch.empty(sc.out_numel(), dtype=torch.float64, device=dev)
+    comm = Communicator(rank, world)  # a 1-rank communicator still runs the real RCCL call
+    sc.prepare()
+    for _ in range(warmup):
+        sc.execute(A, B, C, comm=comm, scratch=partial)
+    _barrier(world)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
+    for _ in range(steps):
+        sc.execute(A, B, C, comm=comm, scratch=partial)
+    _barrier(world)
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    kernel_ms = sc.plan.time(A, B, partial, warmup=1, iters=max(2, args.steps // 2))
-    flops_job = 2 * n ** 6
-    value = flops_job / (elapsed / args.steps) * 1e-12
+    # the same GEMMs without the collectives
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        for c in range(sc.nchunks):
+            plan, oa, ob, op, _, elems = sc.chunk(c)
+            plan.execute(A[oa:], B[ob:], partial[op:op + elems])
+    torch.cuda.synchronize()
+    gemm_only = time.perf_counter() - t1
+    elapsed, gemm_only = _max_over_ranks([elapsed, gemm_only], world, dev, backend)
+    flops = 2 * n ** 6
+    out = {
+        "workload": "BASELINE configs[3] variant: abij=aeim,ebmj fp64, all extents %d, contracted index e split over "
+                    "%d GPU(s), %d pipelined RCCL reduce-scatter(s) of C (%d MB in all) per step"
+                    % (n, world, sc.nchunks, sc.full_c_numel() * 8 // 1000000),
+        "scaling": "strong", "n_gpus": world, "steps": steps,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "tflops": round(flops / (elapsed / steps) * 1e-12, 3),
+        "ms_per_step_gemms_only": round(gemm_only / steps * 1e3, 4),
+        "collective": "ncclReduceScatter x %d on a second stream, issued by libctc_tc.so" % sc.nchunks,
+    }
+    del comm
+    return out
+
+
+def run_config4(world, rank, dev, backend, steps, warmup):
+    """BASELINE configs[3], first variant: abcijk=adij,bcdk fp64, free extents 40, d = 64 (|C| = 32.8 GB),
+    free index a split over the ranks (40 / N each): no collective, strong scaling."""
+    n, d = 40, 64
+    if n % world:
+        return {"skipped": "40 is not a multiple of %d" % world}
+    spec = "adij,bcdk->abcijk"
+    full = ctc_amd.Plan(spec, dict(a=n, b=n, c=n, i=n, j=n, k=n, d=d), "f64")
+    plan, off_a, _, _ = full.shard("a", rank, world)
+    a_loc = n // world
+    A = torch.empty(a_loc * d * n * n, dtype=torch.float64, device=dev)
+    B = torch.empty(n * n * d * n, dtype=torch.float64, device=dev)
+    C = torch.empty(a_loc * n ** 5, dtype=torch.float64, device=dev)
+    ctc_amd.fill(A, SEED_A, first=off_a)
+    ctc_amd.fill(B, SEED_B)
+    plan.prepare()
+    for _ in range(warmup):
+        plan.execute(A, B, C)
+    _barrier(world)
+    t0 = time.perf_counter()
+    kernel_ms = plan.time(A, B, C, warmup=0, iters=steps)
+    _barrier(world)
+    elapsed = time.perf_counter() - t0
+    elapsed, kernel_ms = _max_over_ranks([elapsed, kernel_ms], world, dev, backend)
+    flops = 2 * n ** 6 * d
+    tf_rank = plan.flops / (kernel_ms * 1e-3) * 1e-12
+    return {
+        "workload": "BASELINE configs[3]: abcijk=adij,bcdk fp64, free extents 40, d=64, free index a split over %d GPU(s) "
+                    "(%d each), |C| %.1f GB per GPU, no collective" % (world, a_loc, a_loc * n ** 5 * 8e-9),
+        "scaling": "strong", "n_gpus": world, "steps": steps,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "tflops": round(flops / (elapsed / steps) * 1e-12, 3),
+        "per_gpu_kernel_tflops": round(tf_rank, 3), "per_gpu_frac_of_fp64_mfma_peak": round(tf_rank / PEAK_FP64_MFMA_TFLOPS, 4),
+        "per_gpu_c_write_TBps": round(a_loc * n ** 5 * 8 / (kernel_ms * 1e-3) * 1e-12, 3),
+    }
+
+
+def bench_contracted(args, world, rank, dev, backend):
+    """--shard contracted: the contracted-index variant as the headline line."""
+    v = run_contracted(args.extent, world, rank, dev, backend, args.steps, args.warmup)
     if rank == 0:
-        achieved = sc.plan.flops / (kernel_ms * 1e-3) * 1e-12
+        n = args.extent
         print(json.dumps({
             "metric": "achieved TFLOP/s per contraction (fp64, C[a,b,i,j]=A[a,e,i,m]*B[e,b,m,j])",
-            "value": round(value, 3), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "value": v["tflops"], "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": v["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (splitmix64 uniform[-1,1), generated in HBM)",
-            "config": {"workload": "BASELINE configs[3] variant: abij=aeim,ebmj fp64, all extents %d, contracted "
-                                   "index e split over %d GPUs, one reduce-scatter of C (%d MB) per step"
-                                   % (n, world, sc.full_c_numel() * 8 // 1000000),
-                       "collective": "reduce_scatter_tensor" if backend == "nccl" else "gloo all_reduce + slice",
-                       "flops_per_step": flops_job,
-                       "pct_of_fp64_mfma_peak": round(100.0 * value / (PEAK_FP64_MFMA_TFLOPS * world), 2)},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_kernel<double> on one rank's slab (collective not included)",
-                         "kernel_ms": round(kernel_ms, 4), "algorithmic_flops_per_launch": sc.plan.flops},
+            "config": {"workload": v["workload"], "collective": v["collective"], "flops_per_step": 2 * n ** 6,
+                       "ms_per_step_gemms_only": v["ms_per_step_gemms_only"],
+                       "pct_of_fp64_mfma_peak": round(100.0 * v["tflops"] / (PEAK_FP64_MFMA_TFLOPS * world), 2)},
         }))
     if world > 1:
         dist.destroy_process_group()
@@ -171,6 +220,7 @@ def main():
     ap.add_argument("--extent", type=int, default=96, help="extent of every mode (64..96 in BASELINE)")
     ap.add_argument("--cpu-extent", type=int, default=96, help="extent of the CPU-oracle sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (config.variants)")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the result against the CPU oracle")
     ap.add_argument("--shard", choices=("free", "contracted"), default="free")
     ap.add_argument("--prewarm", type=float, default=0.1, help="seconds of untimed load before the warm-up steps")
@@ -249,6 +299,20 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rel_err = float(t[0])
 
+    # Secondary measurements, after and outside the headline's timed region (every rank takes part; a
+    # failure in one of them is reported in its place and does not cost the headline line).
+    variants = {}
+    if not args.no_variants:
+        del C
+        torch.cuda.empty_cache()
+        for name, fn in (("config4_free_index_strong", lambda: run_config4(world, rank, dev, backend, 4, 2)),
+                         ("contracted_index_reduce_scatter", lambda: run_contracted(n, world, rank, dev, backend, 6, 2))):
+            try:
+                variants[name] = fn()
+            except Exception as e:  # noqa: BLE001
+                variants[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+
     if rank == 0:
         s = plan.summary()
         achieved = flops_rank / (kernel_ms * 1e-3) * 1e-12
@@ -272,6 +336,7 @@ def main():
                 "tile": list(s["tile"]), "layout_a": s["layout_a"], "layout_b": s["layout_b"],
                 "flops_per_step": flops_job,
                 "pct_of_fp64_mfma_peak": round(100.0 * value / (PEAK_FP64_MFMA_TFLOPS * world), 2),
+                "variants": variants,
             },
             "roofline": {
                 "bound": "mfma",

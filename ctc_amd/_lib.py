@@ -16,8 +16,18 @@ SYMBOLS = (
     "ctc_tc_plan_create", "ctc_tc_plan_destroy", "ctc_tc_plan_describe", "ctc_tc_plan_get",
     "ctc_tc_plan_shard", "ctc_tc_plan_prepare", "ctc_tc_execute", "ctc_tc_permute",
     "ctc_tc_ttgt_workspace_bytes", "ctc_tc_execute_ttgt", "ctc_tc_fill", "ctc_tc_time_execute",
-    "ctc_tc_grouped_contract", "ctc_tc_execute_noalloc", "ctc_tc_noalloc_scratch_bytes",
+    "ctc_tc_grouped_contract", "ctc_tc_execute_noalloc", "ctc_tc_noalloc_scratch_bytes", "ctc_tc_set_option", "ctc_tc_get_option",
 )
+# contracted-mode sharding over RCCL (also declared in include/ctc_tc.h)
+SHARDED_SYMBOLS = (
+    "ctc_tc_comm_unique_id", "ctc_tc_comm_init_rank", "ctc_tc_comm_init_all", "ctc_tc_comm_destroy",
+    "ctc_tc_sharded_create", "ctc_tc_sharded_destroy", "ctc_tc_sharded_get", "ctc_tc_sharded_chunk_plan",
+    "ctc_tc_sharded_prepare", "ctc_tc_sharded_execute",
+)
+UNIQUE_ID_BYTES = 128
+REDUCE_SCATTER, ALL_REDUCE = 0, 1
+SQ_CHUNKS, SQ_C_ELEMS, SQ_OUT_ELEMS, SQ_WORKSPACE_ELEMS = 0, 1, 2, 3
+SQ_CHUNK_OFF_A, SQ_CHUNK_OFF_B, SQ_CHUNK_OFF_PARTIAL, SQ_CHUNK_OFF_OUT, SQ_CHUNK_ELEMS = 16, 17, 18, 19, 20
 # every symbol include/ctc_fastr.h declares
 FASTR_SYMBOLS = ("ctc_fastr_best_offsets", "ctc_fastr_sw_align", "ctc_fastr_sw_workspace_bytes")
 
@@ -76,6 +86,10 @@ def load():
     L.ctc_tc_execute_noalloc.restype = ctypes.c_int
     L.ctc_tc_execute_noalloc.argtypes = [vp, ctypes.c_double, vp, vp, ctypes.c_double, vp, vp]
     L.ctc_tc_noalloc_scratch_bytes.restype = ctypes.c_int64
+    L.ctc_tc_get_option.restype = ctypes.c_int64
+    L.ctc_tc_get_option.argtypes = [ctypes.c_char_p]
+    L.ctc_tc_set_option.restype = ctypes.c_int
+    L.ctc_tc_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int64]
     L.ctc_tc_permute.restype = ctypes.c_int
     L.ctc_tc_permute.argtypes = [vp, vp, ctypes.c_int, vp, vp, ctypes.c_int, vp]
     L.ctc_tc_ttgt_workspace_bytes.restype = ctypes.c_int64
@@ -90,6 +104,27 @@ def load():
     L.ctc_tc_time_execute.restype = ctypes.c_int
     L.ctc_tc_time_execute.argtypes = [vp, ctypes.c_double, vp, vp, ctypes.c_double, vp, vp,
                                       ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    L.ctc_tc_comm_unique_id.restype = ctypes.c_int
+    L.ctc_tc_comm_unique_id.argtypes = [vp]
+    L.ctc_tc_comm_init_rank.restype = ctypes.c_int
+    L.ctc_tc_comm_init_rank.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, vp]
+    L.ctc_tc_comm_init_all.restype = ctypes.c_int
+    L.ctc_tc_comm_init_all.argtypes = [ctypes.POINTER(vp), ctypes.c_int, vp]
+    L.ctc_tc_comm_destroy.restype = ctypes.c_int
+    L.ctc_tc_comm_destroy.argtypes = [vp]
+    L.ctc_tc_sharded_create.restype = ctypes.c_int
+    L.ctc_tc_sharded_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, vp, ctypes.c_int, ctypes.c_char,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    L.ctc_tc_sharded_destroy.restype = ctypes.c_int
+    L.ctc_tc_sharded_destroy.argtypes = [vp]
+    L.ctc_tc_sharded_get.restype = ctypes.c_int64
+    L.ctc_tc_sharded_get.argtypes = [vp, ctypes.c_int, ctypes.c_int64]
+    L.ctc_tc_sharded_chunk_plan.restype = vp
+    L.ctc_tc_sharded_chunk_plan.argtypes = [vp, ctypes.c_int]
+    L.ctc_tc_sharded_prepare.restype = ctypes.c_int
+    L.ctc_tc_sharded_prepare.argtypes = [vp]
+    L.ctc_tc_sharded_execute.restype = ctypes.c_int
+    L.ctc_tc_sharded_execute.argtypes = [vp, vp, ctypes.c_double, vp, vp, vp, vp, ctypes.c_int64, vp]
     _lib = L
     return L
 

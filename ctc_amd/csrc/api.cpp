@@ -4,7 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <map>
@@ -236,6 +238,21 @@ int grow_workspace(DeviceTables &dt, size_t bytes)
 // batch entries one launch covers: the batch index is a grid dimension
 constexpr int64_t kMaxBatchPerLaunch = 65535;
 
+// When the persistent deferred-store kernel takes over from the classic one: the classic kernel loses
+// |C| / (write bandwidth) per launch whatever K is, the persistent one runs its K loop with one wave per
+// SIMD and leaves the last, partly filled round of tiles uncut.
+constexpr int64_t kStreamMaxK = 512;
+constexpr double kStreamMinTiles = 2048.0;
+int initial_stream_mode()
+{
+    const char *m = getenv("CTC_TC_STREAM");  // 0: never, force: whenever it can run the launch
+    return !m ? 0 : (m[0] == '0' ? 1 : (m[0] == 'f' ? 2 : 0));
+}
+std::atomic<int> g_stream_mode{initial_stream_mode()};
+std::atomic<int64_t> g_launches_classic{0}, g_launches_stream{0}, g_launches_stream_dma{0};  // since load, for tests
+std::atomic<int> g_stream_f64_dma{1};  // 0: fp64 takes the register-staged persistent kernel too (A/B runs)
+std::atomic<int64_t> g_stream_max_k{getenv("CTC_TC_STREAM_MAX_K") ? atoll(getenv("CTC_TC_STREAM_MAX_K")) : kStreamMaxK};
+
 // The split-K workspace a tiled-GEMM plan can ask for on the current device: the largest over the
 // layout variants an execution may fall back to (unaligned operand bases take element loads).
 size_t worst_splitk_bytes(const ctc::Plan &p)
@@ -317,6 +334,27 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     if (la != ctc::kLayoutScalar && (reinterpret_cast<uintptr_t>(g.A) & 15)) la = ctc::kLayoutScalar;
     if (lb != ctc::kLayoutScalar && (reinterpret_cast<uintptr_t>(g.B) & 15)) lb = ctc::kLayoutScalar;
 
+    // A short K under a large C: the persistent kernel that deals the stores of a finished tile out behind
+    // the MFMAs of the next one (gemm_stream_kernels.hip); see ctc_tc_set_option("stream_mode").
+    {
+        const int mode = g_stream_mode.load();
+        const bool off = mode == 1, force = mode == 2;
+        const int64_t max_k = g_stream_max_k.load();
+        const double tiles128 = ((double)p.M / 128.0) * ((double)p.N / 128.0);
+        if (!off && ctc::stream_gemm_supported(p.dtype, la, lb, p.tile.bm, p.tile.bn, g) &&
+            (force || (p.K <= max_k && tiles128 >= kStreamMinTiles))) {
+            g.ka_stride = p.ka_stride;
+            g.kb_stride = p.kb_stride;
+            const bool dma = p.dtype == ctc::kF64 && g_stream_f64_dma.load() != 0 && ctc::stream_gemm_f64_dma_supported(la, lb, g);
+            hipError_t es = dma ? ctc::launch_gemm_stream_f64_dma(la, lb, g, stream)
+                                : ctc::launch_gemm_stream(p.dtype, la, lb, g, stream);
+            if (es != hipSuccess) return fail_hip(es, "persistent contraction kernel launch");
+            (dma ? g_launches_stream_dma : g_launches_stream).fetch_add(1);
+            continue;
+        }
+    }
+
+    g_launches_classic.fetch_add(1);
     ctc::GemmSchedule sch;
     hipError_t e = ctc::schedule_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, &sch);
     if (e != hipSuccess) return fail_hip(e, "contraction schedule");
@@ -435,6 +473,39 @@ extern "C" {
 int ctc_tc_version(void) { return 100; }
 
 const char *ctc_tc_last_error(void) { return g_last_error.c_str(); }
+
+int ctc_tc_set_option(const char *name, int64_t value)
+{
+    if (!name) return fail(CTC_TC_EINVAL, "null option name");
+    const std::string n(name);
+    if (n == "stream_mode") {
+        if (value < 0 || value > 2) return fail(CTC_TC_EINVAL, "stream_mode: 0 automatic, 1 never, 2 whenever possible");
+        g_stream_mode.store((int)value);
+        return CTC_TC_OK;
+    }
+    if (n == "stream_f64_dma") {
+        g_stream_f64_dma.store(value != 0);
+        return CTC_TC_OK;
+    }
+    if (n == "stream_max_k") {
+        g_stream_max_k.store(value);
+        return CTC_TC_OK;
+    }
+    return fail(CTC_TC_EINVAL, "unknown option '" + n + "'");
+}
+
+int64_t ctc_tc_get_option(const char *name)
+{
+    if (!name) return fail(CTC_TC_EINVAL, "null option name");
+    const std::string n(name);
+    if (n == "stream_mode") return g_stream_mode.load();
+    if (n == "stream_max_k") return g_stream_max_k.load();
+    if (n == "stream_f64_dma") return g_stream_f64_dma.load();
+    if (n == "launches_classic") return g_launches_classic.load();
+    if (n == "launches_stream") return g_launches_stream.load();
+    if (n == "launches_stream_f64_dma") return g_launches_stream_dma.load();
+    return fail(CTC_TC_EINVAL, "unknown option '" + n + "'");
+}
 
 int ctc_tc_device_count(void)
 {

@@ -1,0 +1,518 @@
+// Persistent fp64 MFMA GEMM for contractions with a short K under a large C: the stores of a finished
+// 128 x 64 item are dealt out behind the MFMAs of the next one (see gemm_stream_kernels.hip for the
+// scheme; this is its fp64 form), and every byte that travels global -> LDS goes by LDS-DMA
+// (global_load_lds_dwordx4), so the waves hold no staging registers, execute no LDS writes and wait for
+// a load exactly once per K-tile, a whole K-tile after it was issued:
+//   - three LDS stages of one 128 x 32 A tile and one 64 x 32 B tile (48 KB each, no padding);
+//     during K-tile g the DMA of K-tile g + 2 is in flight and that of g + 1 is awaited just before
+//     the barrier that ends g;
+//   - a DMA instruction writes 1 KB of consecutive LDS (16 bytes per lane), so bank conflicts are
+//     removed by choosing WHICH 16-byte chunk a lane fetches instead of by padding:
+//       K-major operand (unit stride along K):  image [row][32 k], chunk c of row r stored at chunk
+//           position c ^ (r & 15): the 16 rows x 2 chunks a fragment read touches cover all 64 banks;
+//       outer-major operand (unit stride along the rows): image [k][rows], chunk c (rows 2c, 2c+1) of
+//           line k stored at position c ^ ((k & 1) << 3): lines k and k + 1 of a fragment land in
+//           different halves of the banks;
+//   - the element offsets of an item (A rows, B columns, C rows, C columns) are copied from the plan's
+//     tables into a four-slot LDS ring by DMA as well, two items ahead.
+// The only ordinary vector-memory instructions left are the stores of C, so the in-order memory
+// counter never makes a wave wait for a store on the way to its operands.
+// Needs vector layouts on both operands, alpha == 1, beta == 0, batch == 1, even M and N, K a multiple of
+// 32 and at least 64, and k offsets that are a multiple of k (one contracted mode, or modes that fuse:
+// ka_stride / kb_stride); everything else takes the register-staged form or the classic kernel.
+#include "gemm_device.hpp"
+#include "kernels.hpp"
+
+#include <type_traits>
+
+namespace ctc {
+
+namespace {
+
+using namespace gemm_detail;
+
+constexpr int kBM = 128, kBN = 64, kBK = 32, kStages = 3;
+constexpr int kABytes = kBM * kBK * 8, kBBytes = kBN * kBK * 8, kStageBytes = kABytes + kBBytes;
+constexpr int kRingEntries = 2 * (kBM + kBN);  // A rows, B columns, C rows, C columns
+constexpr int kRingSlots = 4;
+
+__device__ __forceinline__ void dma16(const void *src, unsigned char *lds_wave_base)
+{
+    typedef __attribute__((address_space(1))) const void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// LDS reads of the main loop are issued from inline assembly: the compiler makes every LDS load it can
+// see wait for ALL outstanding LDS-DMA transfers (it cannot tell that they target another stage), which
+// would drain the operand pipeline at every k-step.  The price: the compiler does not know these loads
+// are asynchronous either, so every value read this way passes through lds_wait() (an s_waitcnt that
+// names the value as an in/out operand) before its first use.
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    typedef __attribute__((address_space(3))) const unsigned char *lptr_t;
+    return (unsigned)(uintptr_t)(lptr_t)p;
+}
+template <int OFF> __device__ __forceinline__ void lds_read64(double &d, unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void lds_read64(int64_t &d, unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <typename V> __device__ __forceinline__ void lds_wait(V &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+template <typename V> __device__ __forceinline__ void lds_wait(V &a, V &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lds_wait(double &a0, double &a1, double &a2, double &a3, double &b0, double &b1)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1));
+}
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>());
+        static_for<I + 1, N>(f);
+    }
+}
+
+// DMA staging of one BR x 32 fp64 operand tile by 4 waves; NI instructions per wave per tile.
+// Address arithmetic is kept off the vector ALU (a wave that feeds the matrix pipe has about sixteen
+// issue slots per MFMA): per item a lane keeps byte POINTERS to what it fetches at k = 0, and a DMA adds
+// a wave-uniform byte offset for the K-tile (and, outer-major, for the line) to one of them.
+template <int LAY, int BR> struct DmaStager {
+    static constexpr bool KMAJ = (LAY != kLayOuterVec);
+    static constexpr int NI = BR * kBK * 8 / 1024 / 4;
+    static constexpr int NPTR = KMAJ ? NI : (BR == 128 ? 2 : 1);
+    const char *ptr[NPTR];
+    int64_t rowoff[NPTR];  // as read from the ring; turned into ptr[] by finish_rows
+    int lane, wave;
+
+    __device__ __forceinline__ void init(int lane_, int wave_)
+    {
+        lane = lane_;
+        wave = wave_;
+    }
+    // index into the item's row table of the row that pointer j belongs to
+    __device__ __forceinline__ int row_index(int j) const
+    {
+        if (KMAJ) return 4 * (wave * NI + j) + (lane >> 4);
+        if (BR == 128) return 2 * (lane ^ (j << 3));
+        return 2 * ((lane & 31) ^ ((lane >> 5) << 3));
+    }
+    // contracted index, within a K-tile, of what pointer j fetches (the lane-dependent part)
+    __device__ __forceinline__ int k_lane(int j) const
+    {
+        if (KMAJ) return 2 * ((lane & 15) ^ ((4 * j + (lane >> 4)) & 15));
+        if (BR == 128) return 0;
+        return lane >> 5;
+    }
+    __device__ __forceinline__ void load_rows(const int64_t *tile_rows)
+    {
+#pragma unroll
+        for (int j = 0; j < NPTR; ++j) rowoff[j] = tile_rows[row_index(j)];
+    }
+    // the same from inside the main loop: issue, then finish_rows() waits
+    __device__ __forceinline__ void load_rows_async(unsigned tile_rows_lds)
+    {
+#pragma unroll
+        for (int j = 0; j < NPTR; ++j) lds_read64<0>(rowoff[j], tile_rows_lds + 8 * row_index(j));
+    }
+    __device__ __forceinline__ void finish_rows(const double *__restrict__ base, int64_t kstride, bool wait)
+    {
+#pragma unroll
+        for (int j = 0; j < NPTR; ++j) {
+            if (wait) lds_wait(rowoff[j]);
+            ptr[j] = reinterpret_cast<const char *>(base + rowoff[j] + k_lane(j) * kstride);
+        }
+    }
+    // instruction i of the K-tile whose first contracted index is k0 (kofs = 8 * k0 * kstride, wave-uniform);
+    // image = the operand's part of a stage.  K is a multiple of the K-tile here, so nothing is masked.
+    template <int i> __device__ __forceinline__ void issue(int64_t kofs, int64_t kstride, unsigned char *image) const
+    {
+        const char *src;
+        if (KMAJ) src = ptr[i] + kofs;
+        else if (BR == 128) src = ptr[i & 1] + (kofs + (int64_t)(wave * NI + i) * 8 * kstride);
+        else src = ptr[0] + (kofs + (int64_t)(2 * (wave * NI + i)) * 8 * kstride);
+        dma16(src, image + (wave * NI + i) * 1024);
+    }
+};
+
+// Byte address, inside the operand's image, of the MFMA fragment element of lane (frow, fk) for row block
+// b (16 rows from w0 + 16 b) and k-step kk (k = 4 kk + fk).  lane_* are per-lane constants from frag_init.
+template <int LAY, int BR> struct FragAddr {
+    static constexpr bool KMAJ = (LAY != kLayOuterVec);
+    int c0, c1;  // KMAJ: c0 = frow * 256 + (fk & 1) * 8 + w0 * 256, c1 = (frow ^ (fk >> 1)) << 4
+                 // outer: c0 / c1 = lane base for even / odd row blocks
+    __device__ __forceinline__ void init(int frow, int fk, int w0)
+    {
+        if (KMAJ) {
+            c0 = (w0 + frow) * 256 + (fk & 1) * 8;
+            c1 = (frow ^ (fk >> 1)) << 4;
+        } else {
+            const int base = fk * BR * 8 + (w0 + frow) * 8, p = fk & 1;
+            c0 = base + 128 * p;
+            c1 = base - 128 * p;
+        }
+    }
+    template <int b, int kk> __device__ __forceinline__ int at() const
+    {
+        if (KMAJ) return c0 + b * 16 * 256 + (c1 ^ (kk << 5));
+        return ((b & 1) ? c1 : c0) + 128 * b + kk * 4 * BR * 8;
+    }
+    // at<b, kk>() split into a register part (to which the caller adds the stage's LDS address) and a
+    // compile-time part that fits the instruction's offset field
+    template <int b, int kk> __device__ __forceinline__ int var() const
+    {
+        if (KMAJ) return c0 + (c1 ^ (kk << 5));
+        return (b & 1) ? c1 : c0;
+    }
+    template <int b, int kk> static constexpr int imm() { return KMAJ ? b * 16 * 256 : 128 * b + kk * 4 * BR * 8; }
+};
+
+template <int LA, int LB>
+__global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParams p)
+{
+    constexpr int BM = kBM, BN = kBN, BK = kBK, WN = 2;
+    constexpr int TM = 4, TN = 2, NMFMA = TM * TN, KSTEPS = BK / 4, NIDX = NMFMA * KSTEPS;
+    typedef Traits<double> Tr;
+    typedef Tr::acc_t acc_t;
+    typedef DmaStager<LA, BM> SA;
+    typedef DmaStager<LB, BN> SB;
+    constexpr int NDMA = SA::NI + SB::NI;            // operand DMAs per wave per K-tile
+    constexpr int STORE_TILES = 2;                   // K-tiles of an item that carry the previous item's stores
+    // the DMAs of a K-tile are all issued before the barrier that ends it
+    constexpr int DMA_FIRST = 3, DMA_STEP = 4;
+    static_assert(DMA_FIRST + DMA_STEP * (NDMA - 1) < (KSTEPS - 1) * NMFMA, "DMA schedule");
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes];
+    __shared__ __attribute__((aligned(16))) int64_t s_ring[kRingSlots][kRingEntries];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm0 = (wave / WN) * (TM * 16);
+    const int wn0 = (wave % WN) * (TN * 16);
+    const int frow = lane & 15;
+    const int fk = lane >> 4;
+
+    const int G = (int)gridDim.x;
+    const int bid = (int)blockIdx.x;
+    const int wslot = (G & 7) == 0 ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
+    const int64_t tiles = (int64_t)p.nbm * p.nbn;
+    if (wslot >= tiles) return;
+    const int n_items = (int)((tiles - wslot + G - 1) / G);
+    const int width = p.group * p.nbn;
+    auto item_origin = [&](int it, int64_t &m0, int64_t &n0) {
+        const int sid = (int)((int64_t)it * G + wslot);
+        const int first_m = (sid / width) * p.group;
+        const int gsz = min(p.nbm - first_m, p.group);
+        m0 = (int64_t)(first_m + (sid % width) % gsz) * BM;
+        n0 = (int64_t)((sid % width) / gsz) * BN;
+    };
+
+    const double *A = static_cast<const double *>(p.A) + p.bat_a[0];
+    const double *B = static_cast<const double *>(p.B) + p.bat_b[0];
+    double *C = static_cast<double *>(p.C) + p.bat_c[0];
+    const int nk = (int)(p.K / BK);
+
+    // Ring slot of item `it`: the four runs of table entries by DMA, one instruction per wave (16 bytes =
+    // two entries per lane).  Entries past the operand's extent repeat its last two rows (finite data whose
+    // products are never stored); stores are bounded by the item's extents, not by sentinel offsets.
+    auto ring_fetch = [&](int it) {
+        int64_t m0, n0;
+        item_origin(it, m0, n0);
+        const bool rows = (wave & 1) == 0;                 // waves 0, 2: row tables; 1, 3: column tables
+        const int64_t *tab = wave == 0 ? p.row_a : (wave == 1 ? p.col_b : (wave == 2 ? p.row_c : p.col_c));
+        const int64_t first = rows ? m0 : n0, lim = rows ? p.M : p.N;
+        // a column run is half an instruction long: only its lower 32 lanes take part
+        int64_t g = first + 2 * (rows ? lane : (lane & 31));
+        if (g > lim - 2) g = lim - 2;  // M and N are even here, so a pair never straddles the end
+        const int dst = (wave >> 1) * (BM + BN) + (rows ? 0 : BM);
+        if (rows || lane < 32) dma16(tab + g, reinterpret_cast<unsigned char *>(&s_ring[it & 3][dst]));
+    };
+
+    SA sa;
+    SB sb;
+    sa.init(lane, wave);
+    sb.init(lane, wave);
+    FragAddr<LA, BM> fa_addr;
+    FragAddr<LB, BN> fb_addr;
+    fa_addr.init(frow, fk, wm0);
+    fb_addr.init(frow, fk, wn0);
+
+    acc_t acc[2][TM][TN];
+
+    // ---- prologue
+    ring_fetch(0);
+    if (n_items > 1) ring_fetch(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    sa.load_rows(&s_ring[0][0]);
+    sb.load_rows(&s_ring[0][BM]);
+    sa.finish_rows(A, p.ka_stride, false);
+    sb.finish_rows(B, p.kb_stride, false);
+    auto issue_tile = [&](int kt, unsigned char *stage) {
+        const int k0 = kt * BK;
+        static_for<0, SA::NI>([&](auto i_t) {
+            sa.template issue<decltype(i_t)::value>((int64_t)k0 * 8 * p.ka_stride, p.ka_stride, stage);
+        });
+        static_for<0, SB::NI>([&](auto i_t) {
+            sb.template issue<decltype(i_t)::value>((int64_t)k0 * 8 * p.kb_stride, p.kb_stride, stage + kABytes);
+        });
+    };
+    issue_tile(0, smem);
+    issue_tile(1, smem + kStageBytes);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");  // K-tile 0 has landed
+    __syncthreads();
+
+    double fa[2][TM], fb[2][TN];
+    const unsigned smem_lds = lds_addr(smem), ring_lds = lds_addr(&s_ring[0][0]);
+    // fragments of k-step KK of the stage at LDS address `stage` into slot S; asynchronous (frags_wait)
+    auto read_frags = [&](auto slot_t, auto kk_t, unsigned stage) {
+        constexpr int S = decltype(slot_t)::value, KK = decltype(kk_t)::value;
+        static_for<0, TM>([&](auto b_t) {
+            constexpr int b = decltype(b_t)::value;
+            lds_read64<FragAddr<LA, BM>::template imm<b, KK>()>(fa[S][b], stage + fa_addr.template var<b, KK>());
+        });
+        static_for<0, TN>([&](auto b_t) {
+            constexpr int b = decltype(b_t)::value;
+            lds_read64<kABytes + FragAddr<LB, BN>::template imm<b, KK>()>(fb[S][b], stage + fb_addr.template var<b, KK>());
+        });
+    };
+    auto frags_wait = [&](auto slot_t) {
+        constexpr int S = decltype(slot_t)::value;
+        static_assert(TM == 4 && TN == 2, "operand list of lds_wait");
+        lds_wait(fa[S][0], fa[S][1], fa[S][2], fa[S][3], fb[S][0], fb[S][1]);
+    };
+    read_frags(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), smem_lds);
+
+    int stage_cur = 0;  // LDS stage of the K-tile being multiplied
+
+    // Stores of the finished item: element (8-byte) stores straight from the accumulator registers, a wave
+    // instruction writing 128 contiguous bytes of four rows.  Per store the vector ALU computes one 64-bit
+    // add (row offset, read from the ring a store ahead, onto the lane's column pointer); the 16-byte
+    // form would cost four register moves, two lane exchanges and four selects per store, and a wave that
+    // feeds the matrix pipe has about sixteen issue slots per MFMA.  alpha == 1 here (anything else takes
+    // the register-staged form), and the stores are always non-temporal: the launcher sends only results
+    // far larger than the Infinity Cache here.
+    constexpr int NSTORE = TM * 4 * TN;  // per wave and item
+    constexpr int SPT = NSTORE / STORE_TILES, SPACING = NIDX / SPT;
+    static_assert(NSTORE % STORE_TILES == 0 && NIDX % SPT == 0 && SPACING >= 2, "store schedule");
+    char *cptr[TN];                      // C + column offset of this lane's column in block j, in bytes
+    int64_t cvoff[TN];
+    int64_t rvoff[2] = {0, 0};           // row offsets: the row being stored and the next one (in flight)
+    bool row_ok[2] = {false, false}, col_ok[TN] = {false, false};
+    int64_t m_lim_prev = 0, n_lim_prev = 0;  // extents of item X-1 inside C (0: nothing to store)
+    // slot: LDS address of the previous item's ring slot
+    auto row_read = [&](auto r_t, unsigned slot) {  // row r_t = i * 4 + r of the wave's 64
+        constexpr int R = decltype(r_t)::value;
+        const int row = wm0 + 16 * (R / 4) + Tr::acc_row(lane, R % 4);
+        lds_read64<8 * (BM + BN)>(rvoff[R & 1], slot + 8 * row);
+        row_ok[R & 1] = row < m_lim_prev;
+    };
+    auto load_cols = [&](unsigned slot) {
+        static_assert(TN == 2, "two column offsets per lane");
+        const int col = wn0 + frow;
+        lds_read64<8 * (BM + BN + BM)>(cvoff[0], slot + 8 * col);
+        lds_read64<8 * (BM + BN + BM + 16)>(cvoff[1], slot + 8 * col);
+        col_ok[0] = col < n_lim_prev;
+        col_ok[1] = col + 16 < n_lim_prev;
+        row_read(std::integral_constant<int, 0>(), slot);
+    };
+    auto finish_cols = [&]() {
+        lds_wait(cvoff[0], cvoff[1]);
+        cptr[0] = reinterpret_cast<char *>(C + cvoff[0]);
+        cptr[1] = reinterpret_cast<char *>(C + cvoff[1]);
+    };
+    auto store_one = [&](auto set_t, auto s_t, unsigned slot) {
+        constexpr int SET = decltype(set_t)::value, S = decltype(s_t)::value;
+        constexpr int R = S / TN, j = S % TN, i = R / 4, r = R % 4;
+        if (j == 0) {
+            lds_wait(rvoff[R & 1]);
+            if (R + 1 < TM * 4) row_read(std::integral_constant<int, R + 1>(), slot);
+        }
+        double *dst = reinterpret_cast<double *>(cptr[j] + 8 * rvoff[R & 1]);
+#ifdef CTC_SX_NOSTORE
+        if (row_ok[R & 1] && col_ok[j] && acc[SET][i][j][r] == 1.2345e300) __builtin_nontemporal_store(acc[SET][i][j][r], dst);
+#else
+        if (row_ok[R & 1] && col_ok[j]) __builtin_nontemporal_store(acc[SET][i][j][r], dst);
+#endif
+    };
+
+    // One K-tile of the stream: K-tile kt of item X into accumulator set SET.
+    //   VAR 0, 1: K-tile kt == VAR, carrying stores [VAR * SPT, (VAR + 1) * SPT) of item X-1 (set SET ^ 1);
+    //             VAR 0 also starts the accumulators from zero and fetches the ring slot of item X+2;
+    //   VAR 2:    any later K-tile.
+    auto tile_step = [&](auto set_t, auto var_t, int X, int kt) {
+        constexpr int SET = decltype(set_t)::value, VAR = decltype(var_t)::value;
+        const unsigned cur = smem_lds + stage_cur * kStageBytes;
+        const int stage_next = stage_cur == kStages - 1 ? 0 : stage_cur + 1;
+        const int stage_load = stage_next == kStages - 1 ? 0 : stage_next + 1;
+        const unsigned nxt = smem_lds + stage_next * kStageBytes;
+        unsigned char *ld = smem + stage_load * kStageBytes;
+        stage_cur = stage_next;
+        const bool has_next = X + 1 < n_items, has_next2 = X + 2 < n_items;
+        int kt2 = kt + 2;
+        if (kt2 >= nk) kt2 -= nk;
+        const int k0_load = kt2 * BK;
+        const int64_t kofs_a = (int64_t)k0_load * 8 * p.ka_stride, kofs_b = (int64_t)k0_load * 8 * p.kb_stride;
+        const bool loader_switch = (kt == nk - 2) && has_next;
+        const unsigned slot_prev = ring_lds + ((X + 3) & 3) * (kRingEntries * 8);
+        const unsigned slot_next = ring_lds + ((X + 1) & 3) * (kRingEntries * 8);
+        static_for<0, KSTEPS>([&](auto kk_t) {
+            constexpr int kk = decltype(kk_t)::value;
+            constexpr int s = kk & 1;
+            constexpr bool last = (kk == KSTEPS - 1);
+            if (last) {
+                // K-tile +1 has landed: the memory counter retires in order and this wave has issued at
+                // least its NDMA operand DMAs since (stores and the ring DMA are issued only where they
+                // apply, so they cannot be counted on: when they were issued, the oldest of them are waited
+                // for as well, some 40 MFMAs after their issue).  Then the barrier: every wave's part of
+                // K-tile +1 is in LDS, and every wave is done reading the stage the next DMAs overwrite.
+                // A bare s_barrier: __syncthreads() carries a fence, and with LDS-DMA in flight the compiler
+                // turns that fence into a full drain of the memory counter.  What the fence would order is
+                // ordered by hand here: this wave's DMAs of K-tile +1 have landed (vmcnt), its LDS reads of
+                // the stage about to be overwritten have returned (lgkmcnt).
+#ifdef CTC_SX_NOWAITV  // diagnostic builds (wrong results): tools/build_variant.sh
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+#endif
+#ifndef CTC_SX_NOBARRIER
+                __builtin_amdgcn_s_barrier();
+#endif
+            }
+            frags_wait(std::integral_constant<int, s>());
+            static_for<0, NMFMA>([&](auto q_t) {
+                constexpr int q = decltype(q_t)::value;
+                constexpr int idx = kk * NMFMA + q;
+                if (VAR == 0 && kk == 0)
+                    acc[SET][q / TN][q % TN] = Tr::mfma(fa[s][q / TN], fb[s][q % TN], zero_of<acc_t>());
+                else
+                    acc[SET][q / TN][q % TN] = Tr::mfma(fa[s][q / TN], fb[s][q % TN], acc[SET][q / TN][q % TN]);
+                // fragments of the next k-step (of the next K-tile in the last k-step)
+                if (q == 0) {
+                    if (last) read_frags(std::integral_constant<int, s ^ 1>(), std::integral_constant<int, 0>(), nxt);
+                    else read_frags(std::integral_constant<int, s ^ 1>(), std::integral_constant<int, (kk + 1) % KSTEPS>(), cur);
+                }
+                // the loader moves on to the next item's rows before this tile's first DMA
+                if (idx == 1 && loader_switch) {
+                    sa.load_rows_async(slot_next);
+                    sb.load_rows_async(slot_next + 8 * BM);
+                }
+                if (idx == 2 && loader_switch) {
+                    sa.finish_rows(A, p.ka_stride, true);
+                    sb.finish_rows(B, p.kb_stride, true);
+                }
+                // operand DMAs of stream tile +2
+#ifndef CTC_SX_NODMA
+                static_for<0, NDMA>([&](auto u_t) {
+                    constexpr int u = decltype(u_t)::value;
+                    if (idx == DMA_FIRST + DMA_STEP * u) {
+                        if constexpr (u < SA::NI) sa.template issue<u>(kofs_a, p.ka_stride, ld);
+                        else sb.template issue<u - SA::NI>(kofs_b, p.kb_stride, ld + kABytes);
+                    }
+                });
+#endif
+                // item bookkeeping
+                if (VAR == 0 && idx == 0) load_cols(slot_prev);
+                if (VAR == 0 && idx == 1) finish_cols();
+                if (VAR == 0 && idx == NIDX - NMFMA - 2 && has_next2) ring_fetch(X + 2);
+                // stores of the previous item, one every SPACING MFMAs
+                if (VAR < STORE_TILES) {
+                    static_for<0, SPT>([&](auto u_t) {
+                        constexpr int u = decltype(u_t)::value;
+                        constexpr int S = (VAR < STORE_TILES ? VAR : 0) * SPT + u;
+                        if (idx == u * SPACING + (SPACING > 2 ? 2 : 1))
+                            store_one(std::integral_constant<int, SET ^ 1>(), std::integral_constant<int, S>(), slot_prev);
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    };
+
+    auto run_item = [&](auto set_t, int X) {
+        tile_step(set_t, std::integral_constant<int, 0>(), X, 0);
+        tile_step(set_t, std::integral_constant<int, 1>(), X, 1);
+        for (int kt = STORE_TILES; kt < nk; ++kt) tile_step(set_t, std::integral_constant<int, 2>(), X, kt);
+        // this item is the "previous item" of the next one
+        int64_t m0, n0;
+        item_origin(X, m0, n0);
+        m_lim_prev = p.M - m0;
+        n_lim_prev = p.N - n0;
+    };
+
+    for (int X = 0; X < n_items; X += 2) {
+        run_item(std::integral_constant<int, 0>(), X);
+        if (X + 1 < n_items) run_item(std::integral_constant<int, 1>(), X + 1);
+    }
+
+    // the last item's stores: nothing left to hide them behind
+    auto flush = [&](auto set_t, const int64_t *slot) {
+        constexpr int SET = decltype(set_t)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm0 + 16 * i + Tr::acc_row(lane, r);
+                const int64_t ro = slot[BM + BN + row];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = wn0 + 16 * j + frow;
+                    if (row < m_lim_prev && col < n_lim_prev)
+                        __builtin_nontemporal_store(acc[SET][i][j][r], C + ro + slot[BM + BN + BM + col]);
+                }
+            }
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs past the end of the stream have landed before the LDS goes away
+    const int64_t *slot_last = &s_ring[(n_items - 1) & 3][0];
+    if ((n_items - 1) & 1) flush(std::integral_constant<int, 1>(), slot_last);
+    else flush(std::integral_constant<int, 0>(), slot_last);
+}
+
+template <int LA, int LB> hipError_t launch_one(const GemmParams &p, hipStream_t stream)
+{
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    GemmParams q = p;
+    q.nbm = (int)((p.M + kBM - 1) / kBM);
+    q.nbn = (int)((p.N + kBN - 1) / kBN);
+    if (q.group < 1) q.group = 1;
+    const int64_t tiles = (int64_t)q.nbm * q.nbn;
+    if (tiles > 0x7FFFFFFF) return hipErrorInvalidValue;
+    const int grid = (int)(tiles < cus ? tiles : cus);
+    hipLaunchKernelGGL((gemm_stream_f64_kernel<LA, LB>), dim3((unsigned)grid), dim3(256), 0, stream, q);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool stream_gemm_f64_dma_supported(int layout_a, int layout_b, const GemmParams &p)
+{
+    return (layout_a == 0 || layout_a == 1) && (layout_b == 0 || layout_b == 1) && p.batch == 1 && p.beta == 0.0 &&
+           p.alpha == 1.0 && p.K > kBK && p.K % kBK == 0 && p.M >= 2 && p.N >= 2 && p.M % 2 == 0 && p.N % 2 == 0 &&
+           p.ka_stride > 0 && p.kb_stride > 0;
+}
+
+hipError_t launch_gemm_stream_f64_dma(int layout_a, int layout_b, const GemmParams &p, hipStream_t stream)
+{
+    if (!stream_gemm_f64_dma_supported(layout_a, layout_b, p)) return hipErrorInvalidValue;
+    switch (layout_a * 2 + layout_b) {
+#ifndef CTC_SX_ONE  // diagnostic builds of the outer/outer instantiation only (tools/build_variant.sh)
+    case 0: return launch_one<0, 0>(p, stream);
+    case 1: return launch_one<0, 1>(p, stream);
+    case 2: return launch_one<1, 0>(p, stream);
+#endif
+    case 3: return launch_one<1, 1>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ctc

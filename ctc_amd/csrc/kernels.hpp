@@ -34,6 +34,9 @@ struct GemmParams {
     void *ws = nullptr;
     int c_vec = 1;  // > 1: C may be stored in 16-byte vectors of that many elements along N
     int c_stream = 0;  // 1: C is larger than the Infinity Cache: store it with the non-temporal hint
+    // k_a[k] == k * ka_stride for every k (likewise k_b): the operand's k offsets need no table
+    // (0: they do).  Set by the launcher from the plan.
+    int64_t ka_stride = 0, kb_stride = 0;
 };
 
 struct GemmSchedule {
@@ -49,6 +52,16 @@ hipError_t schedule_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, 
                          GemmSchedule *out);
 hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p,
                        const GemmSchedule &schedule, void *workspace, hipStream_t stream);
+
+// Persistent variant for a short K under a large C (gemm_stream_kernels.hip): stores of a finished tile
+// are dealt out behind the MFMAs of the next one.  f64 / f32, 128 x 128 tiles, vector layouts,
+// 16-byte stores of C, beta == 0, batch == 1; stream_gemm_supported says whether a launch qualifies.
+bool stream_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p);
+hipError_t launch_gemm_stream(int dtype, int layout_a, int layout_b, const GemmParams &p, hipStream_t stream);
+// Its fp64 form with every global -> LDS transfer done by LDS-DMA (gemm_stream_f64_kernels.hip); needs, in
+// addition, even M and N and k offsets that are multiples of k (GemmParams::ka_stride / kb_stride).
+bool stream_gemm_f64_dma_supported(int layout_a, int layout_b, const GemmParams &p);
+hipError_t launch_gemm_stream_f64_dma(int layout_a, int layout_b, const GemmParams &p, hipStream_t stream);
 
 // bf16 operands and result, f32 accumulation (gemm_bf16_kernels.hip): square tiles, bm = 128 or 256
 // (256 only with 16-byte-vector layouts on both operands, otherwise 128 is used), K-tile 64;

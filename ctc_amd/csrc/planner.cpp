@@ -314,6 +314,15 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
     build_table(p, p.ex_m, ga, p.M, p.row_a);
     build_table(p, p.ex_k, ga, p.K, p.k_a);
     build_table(p, p.ex_k, gb, p.K, p.k_b);
+    auto affine = [&](const std::vector<int64_t> &tab) -> int64_t {
+        if (tab.size() < 2) return 0;
+        const int64_t s = tab[1];
+        for (size_t k = 0; k < tab.size(); ++k)
+            if (tab[k] != (int64_t)k * s) return 0;
+        return s;
+    };
+    p.ka_stride = affine(p.k_a);
+    p.kb_stride = affine(p.k_b);
     build_table(p, p.ex_n, gb, p.N, p.col_b);
     build_table(p, p.ex_m, sc, p.M, p.row_c);
     build_table(p, p.ex_n, sc, p.N, p.col_c);

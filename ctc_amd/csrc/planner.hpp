@@ -58,6 +58,8 @@ struct Plan {
     int vec_c = 1;  // elements per 16-byte store of C along its unit-stride N mode (1: element stores)
     Tile tile;
     std::vector<int64_t> row_a, k_a, k_b, col_b, row_c, col_c, bat_a, bat_b, bat_c;
+    // k_a[k] == k * ka_stride for every k (the contracted modes fuse into one stride); 0 when they do not
+    int64_t ka_stride = 0, kb_stride = 0;
 
     // Skinny path (M <= 16, K small, N large): memory-bound, no MFMA.  kSkinnySame:
     // B and C share their unit-stride N mode, vectors run along the fused N index and

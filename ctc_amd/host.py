@@ -67,8 +67,9 @@ class Plan:
     """
 
     def __init__(self, spec, extents, dtype="f64", strides_a=None, strides_b=None, strides_c=None,
-                 _handle=None):
+                 _handle=None, _owned=True):
         self._lib = _lib.load()
+        self._owned = _owned  # False: the handle belongs to another object (a chunk plan of a sharded contraction)
         self.spec = spec
         self.extents = dict(extents)
         self.dtype = _dtype_code(dtype)
@@ -85,9 +86,9 @@ class Plan:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and self._lib is not None:
+        if h is not None and self._lib is not None and getattr(self, "_owned", True):
             self._lib.ctc_tc_plan_destroy(h)
-            self._h = None
+        self._h = None
 
     # ---- planner outputs -------------------------------------------------
     def get(self, query):
@@ -264,6 +265,17 @@ def grouped_contract(problems, A, B, C, alpha=1.0, beta=0.0, stream=None):
     check(L.ctc_tc_grouped_contract(_ptr(problems), count, _dtype_code(A.dtype), float(alpha), _ptr(A), _ptr(B),
                                     float(beta), _ptr(C), _stream(stream)))
     return C
+
+
+def set_option(name, value):
+    """Process-wide kernel-selection knob (ctc_tc_set_option): "stream_mode" 0 auto / 1 never / 2 whenever
+    possible, "stream_max_k"."""
+    check(_lib.load().ctc_tc_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    """Value of a knob, or of a launch counter ("launches_classic", "launches_stream", "launches_stream_f64_dma")."""
+    return int(check(_lib.load().ctc_tc_get_option(name.encode())))
 
 
 def noalloc_scratch_bytes():

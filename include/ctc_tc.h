@@ -119,6 +119,24 @@ int ctc_tc_version(void);
  * engine's `throw "literal"` + top-level print (engine/src/execute_engine.cpp:96-99). */
 const char *ctc_tc_last_error(void);
 
+/*
+ * Process-wide kernel-selection knobs, for measurements and tests (production code never needs them):
+ *   "stream_mode"   0 (default): contractions with a short K under a large C run on the persistent
+ *                   deferred-store kernel, everything else on the one-tile-per-workgroup kernel;
+ *                   1: never the persistent kernel; 2: the persistent kernel whenever it can run the
+ *                   launch (f64 / f32, 16-byte-vector layouts, 16-byte stores of C, beta == 0, one
+ *                   batch entry, K > 32);
+ *   "stream_max_k"  largest K the automatic choice sends to the persistent kernel (default 512);
+ *   "stream_f64_dma" 1 (default): fp64 launches that qualify (even M and N, one stride per operand along
+ *                   K) take the persistent kernel's LDS-DMA form; 0: its register-staged form.
+ * No reference counterpart.
+ */
+int ctc_tc_set_option(const char *name, int64_t value);
+/* Value of a knob above, or of a read-only counter of tiled-GEMM launches since the library was loaded:
+ * "launches_classic", "launches_stream" (persistent, register-staged), "launches_stream_f64_dma".
+ * Negative ctc_tc_status for an unknown name. */
+int64_t ctc_tc_get_option(const char *name);
+
 /* Number of usable HIP devices (0 when there is none; never fails). */
 int ctc_tc_device_count(void);
 
@@ -155,6 +173,69 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
  */
 int ctc_tc_plan_shard(const ctc_tc_plan *plan, char mode, int rank, int nranks,
                       ctc_tc_plan **shard, int64_t *off_a, int64_t *off_b, int64_t *off_c);
+
+/*
+ * ---- Contracted-mode sharding with RCCL (one rank per GPU) ---------------------------------------
+ * No reference counterpart: the reference is single-device (apps/fastr/IndelRealigner.cpp:805-829).
+ *
+ * Every rank holds its slab of A and of B along a CONTRACTED mode (packed, extent/p along that mode)
+ * and computes a partial C; the partials are summed over the ranks.  C is cut into chunks along its
+ * slowest mode and the sum of chunk i runs on a second stream while chunk i+1 is multiplied.
+ *   CTC_TC_REDUCE_SCATTER  rank r ends up with the flat range [r |C|/p, (r+1) |C|/p) of the packed C in
+ *                          its output buffer (|C|/p elements); needs a workspace of |C| elements for
+ *                          the partial result.  Chunks are interleaved so that this ownership holds
+ *                          (needs the extent of C's slowest mode to be a multiple of p; otherwise one
+ *                          un-pipelined reduce-scatter of the whole partial result is used).
+ *   CTC_TC_ALL_REDUCE      every rank ends up with the whole C in its output buffer (|C| elements);
+ *                          no workspace.
+ * Communicators are plain RCCL communicators (ncclComm_t) passed as void*.  A host that has none
+ * creates them here: rank 0 calls ctc_tc_comm_unique_id and sends the CTC_TC_UNIQUE_ID_BYTES bytes to
+ * the other ranks by whatever means it has; every rank then calls ctc_tc_comm_init_rank with its
+ * device current.  A single process that drives several GPUs calls ctc_tc_comm_init_all.
+ */
+#define CTC_TC_UNIQUE_ID_BYTES 128
+enum ctc_tc_reduce { CTC_TC_REDUCE_SCATTER = 0, CTC_TC_ALL_REDUCE = 1 };
+enum ctc_tc_sharded_query {
+    CTC_TC_SQ_CHUNKS = 0,           /* number of chunks the execution is cut into */
+    CTC_TC_SQ_C_ELEMS = 1,          /* |C| */
+    CTC_TC_SQ_OUT_ELEMS = 2,        /* elements of the rank's output buffer */
+    CTC_TC_SQ_WORKSPACE_ELEMS = 3,  /* elements of the workspace (0: none needed) */
+    /* per chunk (for hosts that emulate or inspect the pipeline): element offsets of the chunk's GEMM
+     * into the rank-local A and B, into the partial buffer (reduce-scatter) or C (all-reduce), into
+     * the rank's output (reduce-scatter), and the elements of C the chunk covers over all ranks */
+    CTC_TC_SQ_CHUNK_OFF_A = 16,
+    CTC_TC_SQ_CHUNK_OFF_B = 17,
+    CTC_TC_SQ_CHUNK_OFF_PARTIAL = 18,
+    CTC_TC_SQ_CHUNK_OFF_OUT = 19,
+    CTC_TC_SQ_CHUNK_ELEMS = 20
+};
+typedef struct ctc_tc_sharded ctc_tc_sharded;
+
+int ctc_tc_comm_unique_id(void *id128);
+int ctc_tc_comm_init_rank(void **comm, int nranks, int rank, const void *id128);
+int ctc_tc_comm_init_all(void **comms, int ndev, const int *devices /* NULL: 0..ndev-1 */);
+int ctc_tc_comm_destroy(void *comm);
+
+/* extents are those of the WHOLE contraction; `mode` must be a contracted mode whose extent is a
+ * multiple of nranks; nchunks is the wanted pipeline depth (the largest count <= nchunks that divides
+ * the rows evenly is taken; 1 = no overlap).  Host only, needs no GPU. */
+int ctc_tc_sharded_create(const char *spec, int n_ext, const char *mode_names, const int64_t *extents,
+                          int dtype, char mode, int rank, int nranks, int nchunks, int reduce,
+                          ctc_tc_sharded **out);
+int ctc_tc_sharded_destroy(ctc_tc_sharded *s);
+int64_t ctc_tc_sharded_get(const ctc_tc_sharded *s, int query, int64_t chunk);
+/* the plan of one chunk's GEMM (owned by `s`); its C is the chunk's piece of the partial buffer */
+ctc_tc_plan *ctc_tc_sharded_chunk_plan(const ctc_tc_sharded *s, int chunk);
+/* uploads every chunk's tables and creates the communication stream on the current device */
+int ctc_tc_sharded_prepare(ctc_tc_sharded *s);
+/* C_out = alpha * sum over ranks of contract(A_local, B_local), enqueued: the GEMMs on `stream`, the
+ * collectives on the object's own stream; `stream` waits for the last collective before the call's
+ * successors run.  nccl_comm may be NULL when nranks == 1, and for the all-reduce form (the call
+ * then only multiplies and leaves this rank's partial C in C_out for the caller to sum).  beta is not offered: a C that every rank
+ * adds in would be counted p times. */
+int ctc_tc_sharded_execute(ctc_tc_sharded *s, void *nccl_comm, double alpha, const void *A_local,
+                           const void *B_local, void *C_out, void *workspace, int64_t workspace_bytes,
+                           void *stream);
 
 /* Set-up of a plan on the current device, ahead of the first execution: uploads the offset
  * tables, allocates the workspace the plan's executions will use (split-K partial sums for every

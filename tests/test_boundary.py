@@ -54,10 +54,12 @@ def test_contract_plugin_command_line():
                                                shard="a:1/4", dtype="f32"))
     assert cmds[0].split()[-2:] == ["--shard", "a:1/4"] and "--dtype f32" in cmds[0]
     cmds = eb.plugin_commands("contract", dict(spec="s", extents="e", input_a="a", input_b="b", output_c="c", ngpu="8"))
-    assert cmds[0].split()[-4:] == ["--ngpu", "8", "--shard-on", "auto"] and "--shard " not in cmds[0]
+    assert cmds[0].split()[-2:] == ["--ngpu", "8"] and "--shard" not in cmds[0]
     cmds = eb.plugin_commands("contract", dict(spec="s", extents="e", input_a="a", input_b="b", output_c="c", ngpu="4",
                                                shard_on="i"))
     assert cmds[0].split()[-4:] == ["--ngpu", "4", "--shard-on", "i"]
+    cmds = eb.plugin_commands("contract", dict(spec="s", extents="e", input_a="a", input_b="b", output_c="c", shard_on="e"))
+    assert cmds[0].split()[-2:] == ["--shard-on", "e"] and "--ngpu" not in cmds[0]  # one rank, still the sharded path
 
 
 def test_cli_command_composition():
@@ -150,10 +152,16 @@ def test_other_element_types_through_the_unchanged_engine(tmp_path, oracle, dtyp
     ("aeim,ebmj=abij", dict(a=8, b=6, e=5, i=7, j=4, m=3), "3", "auto"),   # a does not divide by 3: b is taken
     ("aeim,ebmj=abij", dict(a=5, b=6, e=5, i=7, j=4, m=3), "4", "j"),      # fastest mode of C: interleaved runs
     ("adij,bcdk=abcijk", dict(a=4, b=3, c=2, d=16, i=6, j=5, k=8), "4", "k"),
+    # contracted modes: slabs of A and B, partial results summed (RCCL with one rank per GPU; ranks that
+    # share the box's one GPU are summed on the host; one rank runs the real one-rank RCCL reduce-scatter)
+    ("aeim,ebmj=abij", dict(a=8, b=6, e=6, i=7, j=4, m=3), "2", "e"),
+    ("aeim,ebmj=abij", dict(a=8, b=6, e=6, i=7, j=4, m=4), "4", "m"),
+    ("aeim,ebmj=abij", dict(a=8, b=6, e=6, i=7, j=4, m=3), "1", "e"),
+    ("adij,bcdk=abcijk", dict(a=4, b=3, c=2, d=16, i=6, j=5, k=8), "1", "d"),
 ])
 def test_whole_contraction_on_several_gpus_through_the_unchanged_engine(tmp_path, oracle, spec, ext, ngpu, shard_on):
-    """--ngpu: one process, one host thread per slab of a free mode (ranks share the devices the box
-    has), slabs of C merged on the host; the file must equal the oracle's unsharded result."""
+    """--ngpu: one process, one host thread per slab (ranks share the devices the box has), every rank
+    holding only its slabs; the file must equal the oracle's unsharded result."""
     if not os.path.exists(ENGINE):
         pytest.fail("oracle/_ref/execute_engine missing: run oracle/build_ref.sh where /root/reference exists")
     ins, outm = spec.split("=")
@@ -191,8 +199,10 @@ def test_several_gpus_with_beta_and_bad_requests(tmp_path, oracle):
     want = oracle.contract("adc,db->abc", ext, A, B, C=C0.copy(), alpha=0.5, beta=-2.0)
     got = np.fromfile(tmp_path / "C.bin", dtype=np.float64)
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
-    for extra in (["--ngpu", "2", "--shard-on", "d"], ["--ngpu", "7"], ["--ngpu", "2", "--shard", "a:0/2"]):
-        run = subprocess.run(base + extra, capture_output=True, text=True)   # contracted mode; nothing divides by 7; both kinds of sharding
+    for extra in (["--ngpu", "2", "--shard-on", "d", "--beta", "1"], ["--ngpu", "7"], ["--ngpu", "2", "--shard", "a:0/2"],
+                  ["--ngpu", "2", "--shard-on", "d"]):
+        # beta with a contracted mode; nothing divides by 7; both kinds of sharding; 7 does not divide by 2
+        run = subprocess.run(base + extra, capture_output=True, text=True)
         assert run.returncode != 0 and "ctc_contract:" in run.stderr, extra
 
 

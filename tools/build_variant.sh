@@ -9,5 +9,5 @@ mkdir -p ../lib/variants /tmp/ctc_variants
 SRC=${3:-gemm_kernels}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$ROOT/include" -I. $2 -c $SRC.hip -o /tmp/ctc_variants/${SRC}_$1.o
 OBJS=$(ls ../build/*.o | grep -v "/$SRC.o")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libctc_tc_$1.so $OBJS /tmp/ctc_variants/${SRC}_$1.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libctc_tc_$1.so $OBJS /tmp/ctc_variants/${SRC}_$1.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo built ../lib/variants/libctc_tc_$1.so
