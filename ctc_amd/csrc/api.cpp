@@ -241,7 +241,10 @@ constexpr int64_t kMaxBatchPerLaunch = 65535;
 // When the persistent deferred-store kernel takes over from the classic one: the classic kernel loses
 // |C| / (write bandwidth) per launch whatever K is, the persistent one runs its K loop with one wave per
 // SIMD and leaves the last, partly filled round of tiles uncut.
-constexpr int64_t kStreamMaxK = 512;
+// Measured on MI355X (tools/stream_cmp.py): the persistent kernel wins up to K = 128 in fp64 (K = 64: 41 ->
+// 49 TFLOP/s, K = 128: 56 -> 59) and loses from K = 256 on (K = 512: 67 -> 64); the fp32 form wins at K = 64
+// (44 -> 55) and is level at K = 128.
+constexpr int64_t kStreamMaxK = 128;
 constexpr double kStreamMinTiles = 2048.0;
 int initial_stream_mode()
 {
@@ -342,7 +345,7 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
         const int64_t max_k = g_stream_max_k.load();
         const double tiles128 = ((double)p.M / 128.0) * ((double)p.N / 128.0);
         if (!off && ctc::stream_gemm_supported(p.dtype, la, lb, p.tile.bm, p.tile.bn, g) &&
-            (force || (p.K <= max_k && tiles128 >= kStreamMinTiles))) {
+            (force || (p.K <= (p.dtype == ctc::kF32 && max_k > 96 ? 96 : max_k) && tiles128 >= kStreamMinTiles))) {
             g.ka_stride = p.ka_stride;
             g.kb_stride = p.kb_stride;
             const bool dma = p.dtype == ctc::kF64 && g_stream_f64_dma.load() != 0 && ctc::stream_gemm_f64_dma_supported(la, lb, g);

@@ -23,6 +23,7 @@
 #include "gemm_device.hpp"
 #include "kernels.hpp"
 
+#include <cstdio>
 #include <type_traits>
 
 namespace ctc {
@@ -64,6 +65,9 @@ template <int OFF> __device__ __forceinline__ void lds_read64(int64_t &d, unsign
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 template <typename V> __device__ __forceinline__ void lds_wait(V &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+// the same with up to N younger LDS reads still in flight (LDS reads return in order; the caller knows that
+// at least N were issued after the one that fills `a`)
+template <int N, typename V> __device__ __forceinline__ void lds_wait_but(V &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
 template <typename V> __device__ __forceinline__ void lds_wait(V &a, V &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lds_wait(double &a0, double &a1, double &a2, double &a3, double &b0, double &b1)
 {
@@ -85,58 +89,59 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 template <int LAY, int BR> struct DmaStager {
     static constexpr bool KMAJ = (LAY != kLayOuterVec);
     static constexpr int NI = BR * kBK * 8 / 1024 / 4;
-    static constexpr int NPTR = KMAJ ? NI : (BR == 128 ? 2 : 1);
-    const char *ptr[NPTR];
-    int64_t rowoff[NPTR];  // as read from the ring; turned into ptr[] by finish_rows
+    static constexpr int NROW = KMAJ ? NI : (BR == 128 ? 2 : 1);  // distinct rows among the NI fetches
+    const char *ptr[NI];   // what instruction i fetches at k0 = 0
+    int64_t rowoff[NROW];  // as read from the ring; turned into ptr[] by finish_rows
+    int64_t kofs8[NI];     // byte offset of instruction i's k (lane part and line part) from the row at k = 0
     int lane, wave;
 
-    __device__ __forceinline__ void init(int lane_, int wave_)
-    {
-        lane = lane_;
-        wave = wave_;
-    }
-    // index into the item's row table of the row that pointer j belongs to
+    // index into the item's row table of row j
     __device__ __forceinline__ int row_index(int j) const
     {
         if (KMAJ) return 4 * (wave * NI + j) + (lane >> 4);
         if (BR == 128) return 2 * (lane ^ (j << 3));
         return 2 * ((lane & 31) ^ ((lane >> 5) << 3));
     }
-    // contracted index, within a K-tile, of what pointer j fetches (the lane-dependent part)
-    __device__ __forceinline__ int k_lane(int j) const
+    // contracted index, within a K-tile, of what instruction i fetches
+    __device__ __forceinline__ int k_of(int i) const
     {
-        if (KMAJ) return 2 * ((lane & 15) ^ ((4 * j + (lane >> 4)) & 15));
-        if (BR == 128) return 0;
-        return lane >> 5;
+        if (KMAJ) return 2 * ((lane & 15) ^ ((4 * i + (lane >> 4)) & 15));
+        if (BR == 128) return wave * NI + i;
+        return 2 * (wave * NI + i) + (lane >> 5);
+    }
+    __device__ __forceinline__ void init(int lane_, int wave_, int64_t kstride)
+    {
+        lane = lane_;
+        wave = wave_;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) kofs8[i] = 8 * (int64_t)k_of(i) * kstride;
     }
     __device__ __forceinline__ void load_rows(const int64_t *tile_rows)
     {
 #pragma unroll
-        for (int j = 0; j < NPTR; ++j) rowoff[j] = tile_rows[row_index(j)];
+        for (int j = 0; j < NROW; ++j) rowoff[j] = tile_rows[row_index(j)];
     }
     // the same from inside the main loop: issue, then finish_rows() waits
     __device__ __forceinline__ void load_rows_async(unsigned tile_rows_lds)
     {
 #pragma unroll
-        for (int j = 0; j < NPTR; ++j) lds_read64<0>(rowoff[j], tile_rows_lds + 8 * row_index(j));
+        for (int j = 0; j < NROW; ++j) lds_read64<0>(rowoff[j], tile_rows_lds + 8 * row_index(j));
     }
-    __device__ __forceinline__ void finish_rows(const double *__restrict__ base, int64_t kstride, bool wait)
+    __device__ __forceinline__ void finish_rows(const double *__restrict__ base, bool wait)
     {
+        if (wait) {
 #pragma unroll
-        for (int j = 0; j < NPTR; ++j) {
-            if (wait) lds_wait(rowoff[j]);
-            ptr[j] = reinterpret_cast<const char *>(base + rowoff[j] + k_lane(j) * kstride);
+            for (int j = 0; j < NROW; ++j) lds_wait(rowoff[j]);
         }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            ptr[i] = reinterpret_cast<const char *>(base + rowoff[KMAJ ? i : (BR == 128 ? (i & 1) : 0)]) + kofs8[i];
     }
     // instruction i of the K-tile whose first contracted index is k0 (kofs = 8 * k0 * kstride, wave-uniform);
     // image = the operand's part of a stage.  K is a multiple of the K-tile here, so nothing is masked.
-    template <int i> __device__ __forceinline__ void issue(int64_t kofs, int64_t kstride, unsigned char *image) const
+    template <int i> __device__ __forceinline__ void issue(int64_t kofs, unsigned char *image) const
     {
-        const char *src;
-        if (KMAJ) src = ptr[i] + kofs;
-        else if (BR == 128) src = ptr[i & 1] + (kofs + (int64_t)(wave * NI + i) * 8 * kstride);
-        else src = ptr[0] + (kofs + (int64_t)(2 * (wave * NI + i)) * 8 * kstride);
-        dma16(src, image + (wave * NI + i) * 1024);
+        dma16(ptr[i] + kofs, image + (wave * NI + i) * 1024);
     }
 };
 
@@ -204,13 +209,32 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
     const int64_t tiles = (int64_t)p.nbm * p.nbn;
     if (wslot >= tiles) return;
     const int n_items = (int)((tiles - wslot + G - 1) / G);
+    // Items are visited in order, G tile ids apart.  The tile id is kept as (group of tile rows, position
+    // inside the group) and advanced by additions: integer divisions, which the wave would do through
+    // the vector ALU, are left to the last, partly filled group of tile rows.
     const int width = p.group * p.nbn;
-    auto item_origin = [&](int it, int64_t &m0, int64_t &n0) {
-        const int sid = (int)((int64_t)it * G + wslot);
-        const int first_m = (sid / width) * p.group;
+    const int step_grp = G / width, step_rem = G % width;
+    const int group_shift = (p.group & (p.group - 1)) == 0 ? __builtin_ctz((unsigned)p.group) : -1;
+    int fetch_grp = wslot / width, fetch_rem = wslot % width;
+    auto next_origin = [&](int64_t &m0, int64_t &n0) {
+        const int first_m = fetch_grp * p.group;
         const int gsz = min(p.nbm - first_m, p.group);
-        m0 = (int64_t)(first_m + (sid % width) % gsz) * BM;
-        n0 = (int64_t)((sid % width) / gsz) * BN;
+        int tm, tn;
+        if (gsz == p.group && group_shift >= 0) {
+            tm = first_m + (fetch_rem & (p.group - 1));
+            tn = fetch_rem >> group_shift;
+        } else {
+            tm = first_m + fetch_rem % gsz;
+            tn = fetch_rem / gsz;
+        }
+        m0 = (int64_t)tm * BM;
+        n0 = (int64_t)tn * BN;
+        fetch_grp += step_grp;
+        fetch_rem += step_rem;
+        if (fetch_rem >= width) {
+            fetch_rem -= width;
+            fetch_grp += 1;
+        }
     };
 
     const double *A = static_cast<const double *>(p.A) + p.bat_a[0];
@@ -221,9 +245,10 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
     // Ring slot of item `it`: the four runs of table entries by DMA, one instruction per wave (16 bytes =
     // two entries per lane).  Entries past the operand's extent repeat its last two rows (finite data whose
     // products are never stored); stores are bounded by the item's extents, not by sentinel offsets.
-    auto ring_fetch = [&](int it) {
+    int m_lim_new = 0, n_lim_new = 0;  // out of ring_fetch: extents of the item it fetched
+    auto ring_fetch = [&](int it) {  // items must be fetched in order: 0, 1, 2, ...
         int64_t m0, n0;
-        item_origin(it, m0, n0);
+        next_origin(m0, n0);
         const bool rows = (wave & 1) == 0;                 // waves 0, 2: row tables; 1, 3: column tables
         const int64_t *tab = wave == 0 ? p.row_a : (wave == 1 ? p.col_b : (wave == 2 ? p.row_c : p.col_c));
         const int64_t first = rows ? m0 : n0, lim = rows ? p.M : p.N;
@@ -232,12 +257,14 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
         if (g > lim - 2) g = lim - 2;  // M and N are even here, so a pair never straddles the end
         const int dst = (wave >> 1) * (BM + BN) + (rows ? 0 : BM);
         if (rows || lane < 32) dma16(tab + g, reinterpret_cast<unsigned char *>(&s_ring[it & 3][dst]));
+        m_lim_new = (int)(p.M - m0 < BM ? p.M - m0 : BM);
+        n_lim_new = (int)(p.N - n0 < BN ? p.N - n0 : BN);
     };
 
     SA sa;
     SB sb;
-    sa.init(lane, wave);
-    sb.init(lane, wave);
+    sa.init(lane, wave, p.ka_stride);
+    sb.init(lane, wave, p.kb_stride);
     FragAddr<LA, BM> fa_addr;
     FragAddr<LB, BN> fb_addr;
     fa_addr.init(frow, fk, wm0);
@@ -247,20 +274,25 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
 
     // ---- prologue
     ring_fetch(0);
-    if (n_items > 1) ring_fetch(1);
+    int m_lim_0 = m_lim_new, n_lim_0 = n_lim_new, m_lim_1 = 0, n_lim_1 = 0;
+    if (n_items > 1) {
+        ring_fetch(1);
+        m_lim_1 = m_lim_new;
+        n_lim_1 = n_lim_new;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     sa.load_rows(&s_ring[0][0]);
     sb.load_rows(&s_ring[0][BM]);
-    sa.finish_rows(A, p.ka_stride, false);
-    sb.finish_rows(B, p.kb_stride, false);
+    sa.finish_rows(A, false);
+    sb.finish_rows(B, false);
     auto issue_tile = [&](int kt, unsigned char *stage) {
         const int k0 = kt * BK;
         static_for<0, SA::NI>([&](auto i_t) {
-            sa.template issue<decltype(i_t)::value>((int64_t)k0 * 8 * p.ka_stride, p.ka_stride, stage);
+            sa.template issue<decltype(i_t)::value>((int64_t)k0 * 8 * p.ka_stride, stage);
         });
         static_for<0, SB::NI>([&](auto i_t) {
-            sb.template issue<decltype(i_t)::value>((int64_t)k0 * 8 * p.kb_stride, p.kb_stride, stage + kABytes);
+            sb.template issue<decltype(i_t)::value>((int64_t)k0 * 8 * p.kb_stride, stage + kABytes);
         });
     };
     issue_tile(0, smem);
@@ -304,50 +336,70 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
     char *cptr[TN];                      // C + column offset of this lane's column in block j, in bytes
     int64_t cvoff[TN];
     int64_t rvoff[2] = {0, 0};           // row offsets: the row being stored and the next one (in flight)
-    bool row_ok[2] = {false, false}, col_ok[TN] = {false, false};
-    int64_t m_lim_prev = 0, n_lim_prev = 0;  // extents of item X-1 inside C (0: nothing to store)
-    // slot: LDS address of the previous item's ring slot
-    auto row_read = [&](auto r_t, unsigned slot) {  // row r_t = i * 4 + r of the wave's 64
+    unsigned row_lds = 0;                // LDS address of the previous item's C-row offset of this lane's first row
+    // extents inside C (capped at the tile's) of items X-1 (the one being stored; 0: nothing to store), X,
+    // X+1 and X+2: computed where the item's ring slot is requested and shifted along once per item
+    int m_lim_prev = 0, n_lim_prev = 0, m_lim_q[3] = {0, 0, 0}, n_lim_q[3] = {0, 0, 0};
+    // row R = i * 4 + r of the wave's 64: lane (lane >> 4) + 4 r + 16 i, so its ring entry sits at a
+    // compile-time distance from the lane's first row
+    auto row_read = [&](auto r_t) {
         constexpr int R = decltype(r_t)::value;
-        const int row = wm0 + 16 * (R / 4) + Tr::acc_row(lane, R % 4);
-        lds_read64<8 * (BM + BN)>(rvoff[R & 1], slot + 8 * row);
-        row_ok[R & 1] = row < m_lim_prev;
+        lds_read64<8 * (16 * (R / 4) + 4 * (R % 4))>(rvoff[R & 1], row_lds);
     };
+    // slot: LDS address of the previous item's ring slot
     auto load_cols = [&](unsigned slot) {
         static_assert(TN == 2, "two column offsets per lane");
-        const int col = wn0 + frow;
-        lds_read64<8 * (BM + BN + BM)>(cvoff[0], slot + 8 * col);
-        lds_read64<8 * (BM + BN + BM + 16)>(cvoff[1], slot + 8 * col);
-        col_ok[0] = col < n_lim_prev;
-        col_ok[1] = col + 16 < n_lim_prev;
-        row_read(std::integral_constant<int, 0>(), slot);
+        lds_read64<8 * (BM + BN + BM)>(cvoff[0], slot + 8 * (wn0 + frow));
+        lds_read64<8 * (BM + BN + BM + 16)>(cvoff[1], slot + 8 * (wn0 + frow));
+        row_lds = slot + 8 * (BM + BN + wm0 + (lane >> 4));
+        row_read(std::integral_constant<int, 0>());
     };
     auto finish_cols = [&]() {
         lds_wait(cvoff[0], cvoff[1]);
         cptr[0] = reinterpret_cast<char *>(C + cvoff[0]);
         cptr[1] = reinterpret_cast<char *>(C + cvoff[1]);
     };
-    auto store_one = [&](auto set_t, auto s_t, unsigned slot) {
+    // FULL: the item lies wholly inside C, no lane is masked
+    auto store_one = [&](auto set_t, auto s_t, auto full_t) {
         constexpr int SET = decltype(set_t)::value, S = decltype(s_t)::value;
+        constexpr bool FULL = decltype(full_t)::value;
         constexpr int R = S / TN, j = S % TN, i = R / 4, r = R % 4;
         if (j == 0) {
-            lds_wait(rvoff[R & 1]);
-            if (R + 1 < TM * 4) row_read(std::integral_constant<int, R + 1>(), slot);
+            // this row's offset was requested at the previous row's first store, one k-step ago; the only
+            // LDS reads issued since are the TM + TN fragment reads that open this k-step (when the loader
+            // switched items in between, its reads were waited for in full)
+            if (R == 0) lds_wait(rvoff[0]);
+            else lds_wait_but<TM + TN>(rvoff[R & 1]);
+            if (R + 1 < TM * 4) row_read(std::integral_constant<int, R + 1>());
         }
-        double *dst = reinterpret_cast<double *>(cptr[j] + 8 * rvoff[R & 1]);
-#ifdef CTC_SX_NOSTORE
-        if (row_ok[R & 1] && col_ok[j] && acc[SET][i][j][r] == 1.2345e300) __builtin_nontemporal_store(acc[SET][i][j][r], dst);
-#else
-        if (row_ok[R & 1] && col_ok[j]) __builtin_nontemporal_store(acc[SET][i][j][r], dst);
+        // one vector-ALU instruction per store: (row offset << 3) + column pointer
+        // (typed as a global-memory pointer: a generic one would make the store a FLAT instruction, which
+        // the compiler orders behind every LDS-DMA in flight)
+        typedef __attribute__((address_space(1))) double *gptr_t;
+        gptr_t dst;
+        asm("v_lshl_add_u64 %0, %1, 3, %2" : "=v"(dst) : "v"(rvoff[R & 1]), "v"(cptr[j]));
+        bool ok = true;
+        if (!FULL) ok = (wm0 + 16 * i + Tr::acc_row(lane, r) < m_lim_prev) && (wn0 + 16 * j + frow < n_lim_prev);
+#if defined(CTC_SX_NOSTORE)
+        ok = ok && acc[SET][i][j][r] == 1.2345e300;
 #endif
+        if (ok) __builtin_nontemporal_store(acc[SET][i][j][r], dst);
     };
 
-    // One K-tile of the stream: K-tile kt of item X into accumulator set SET.
-    //   VAR 0, 1: K-tile kt == VAR, carrying stores [VAR * SPT, (VAR + 1) * SPT) of item X-1 (set SET ^ 1);
-    //             VAR 0 also starts the accumulators from zero and fetches the ring slot of item X+2;
-    //   VAR 2:    any later K-tile.
-    auto tile_step = [&](auto set_t, auto var_t, int X, int kt) {
+#ifdef CTC_SX_STAMPS  // diagnostic build: shader-clock ticks per K-tile kind, split at the wait + barrier
+    unsigned long long st_body[3] = {0, 0, 0}, st_sync[3] = {0, 0, 0}, st_n[3] = {0, 0, 0}, st_t0 = 0, st_t1 = 0, st_t2 = 0;
+#define CTC_SX_STAMP(var)                                                        \
+    do {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+#else
+#define CTC_SX_STAMP(var) do { } while (0)
+#endif
+    auto tile_step = [&](auto set_t, auto var_t, auto full_t, int X, int kt) {
         constexpr int SET = decltype(set_t)::value, VAR = decltype(var_t)::value;
+        CTC_SX_STAMP(st_t0);
         const unsigned cur = smem_lds + stage_cur * kStageBytes;
         const int stage_next = stage_cur == kStages - 1 ? 0 : stage_cur + 1;
         const int stage_load = stage_next == kStages - 1 ? 0 : stage_next + 1;
@@ -376,6 +428,7 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
                 // turns that fence into a full drain of the memory counter.  What the fence would order is
                 // ordered by hand here: this wave's DMAs of K-tile +1 have landed (vmcnt), its LDS reads of
                 // the stage about to be overwritten have returned (lgkmcnt).
+                CTC_SX_STAMP(st_t1);
 #ifdef CTC_SX_NOWAITV  // diagnostic builds (wrong results): tools/build_variant.sh
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
@@ -384,6 +437,7 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
 #ifndef CTC_SX_NOBARRIER
                 __builtin_amdgcn_s_barrier();
 #endif
+                CTC_SX_STAMP(st_t2);
             }
             frags_wait(std::integral_constant<int, s>());
             static_for<0, NMFMA>([&](auto q_t) {
@@ -404,16 +458,16 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
                     sb.load_rows_async(slot_next + 8 * BM);
                 }
                 if (idx == 2 && loader_switch) {
-                    sa.finish_rows(A, p.ka_stride, true);
-                    sb.finish_rows(B, p.kb_stride, true);
+                    sa.finish_rows(A, true);
+                    sb.finish_rows(B, true);
                 }
                 // operand DMAs of stream tile +2
 #ifndef CTC_SX_NODMA
                 static_for<0, NDMA>([&](auto u_t) {
                     constexpr int u = decltype(u_t)::value;
                     if (idx == DMA_FIRST + DMA_STEP * u) {
-                        if constexpr (u < SA::NI) sa.template issue<u>(kofs_a, p.ka_stride, ld);
-                        else sb.template issue<u - SA::NI>(kofs_b, p.kb_stride, ld + kABytes);
+                        if constexpr (u < SA::NI) sa.template issue<u>(kofs_a, ld);
+                        else sb.template issue<u - SA::NI>(kofs_b, ld + kABytes);
                     }
                 });
 #endif
@@ -427,23 +481,46 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
                         constexpr int u = decltype(u_t)::value;
                         constexpr int S = (VAR < STORE_TILES ? VAR : 0) * SPT + u;
                         if (idx == u * SPACING + (SPACING > 2 ? 2 : 1))
-                            store_one(std::integral_constant<int, SET ^ 1>(), std::integral_constant<int, S>(), slot_prev);
+                            store_one(std::integral_constant<int, SET ^ 1>(), std::integral_constant<int, S>(), full_t);
                     });
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
+#ifdef CTC_SX_STAMPS
+        {
+            unsigned long long st_t3;
+            CTC_SX_STAMP(st_t3);
+            st_body[VAR] += (st_t1 - st_t0) + (st_t3 - st_t2);
+            st_sync[VAR] += st_t2 - st_t1;
+            st_n[VAR] += 1;
+        }
+#endif
     };
 
+    m_lim_q[0] = m_lim_0; n_lim_q[0] = n_lim_0;
+    m_lim_q[1] = m_lim_1; n_lim_q[1] = n_lim_1;
     auto run_item = [&](auto set_t, int X) {
-        tile_step(set_t, std::integral_constant<int, 0>(), X, 0);
-        tile_step(set_t, std::integral_constant<int, 1>(), X, 1);
-        for (int kt = STORE_TILES; kt < nk; ++kt) tile_step(set_t, std::integral_constant<int, 2>(), X, kt);
+        m_lim_new = n_lim_new = 0;  // stays 0 when there is no item X+2
+        // the previous item lies wholly inside C (all but the last tile row / column and "item -1"): its
+        // stores carry no per-lane bounds and no branches
+        const bool prev_full = m_lim_prev == BM && n_lim_prev == BN;
+        if (prev_full) {
+            tile_step(set_t, std::integral_constant<int, 0>(), std::true_type(), X, 0);
+            m_lim_q[2] = m_lim_new;
+            n_lim_q[2] = n_lim_new;
+            tile_step(set_t, std::integral_constant<int, 1>(), std::true_type(), X, 1);
+        } else {
+            tile_step(set_t, std::integral_constant<int, 0>(), std::false_type(), X, 0);
+            m_lim_q[2] = m_lim_new;
+            n_lim_q[2] = n_lim_new;
+            tile_step(set_t, std::integral_constant<int, 1>(), std::false_type(), X, 1);
+        }
+        for (int kt = STORE_TILES; kt < nk; ++kt) tile_step(set_t, std::integral_constant<int, 2>(), std::true_type(), X, kt);
         // this item is the "previous item" of the next one
-        int64_t m0, n0;
-        item_origin(X, m0, n0);
-        m_lim_prev = p.M - m0;
-        n_lim_prev = p.N - n0;
+        m_lim_prev = m_lim_q[0]; n_lim_prev = n_lim_q[0];
+        m_lim_q[0] = m_lim_q[1]; n_lim_q[0] = n_lim_q[1];
+        m_lim_q[1] = m_lim_q[2]; n_lim_q[1] = n_lim_q[2];
     };
 
     for (int X = 0; X < n_items; X += 2) {
@@ -468,6 +545,13 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
                 }
             }
     };
+#ifdef CTC_SX_STAMPS
+    if (t == 0 && (bid == 0 || bid == 77))
+        printf("[stamps] block %d items %d | per K-tile ticks body/sync: first %llu/%llu second %llu/%llu later %llu/%llu (n %llu %llu %llu)\n", bid,
+               n_items, st_body[0] / (st_n[0] ? st_n[0] : 1), st_sync[0] / (st_n[0] ? st_n[0] : 1), st_body[1] / (st_n[1] ? st_n[1] : 1),
+               st_sync[1] / (st_n[1] ? st_n[1] : 1), st_body[2] / (st_n[2] ? st_n[2] : 1), st_sync[2] / (st_n[2] ? st_n[2] : 1), st_n[0],
+               st_n[1], st_n[2]);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs past the end of the stream have landed before the LDS goes away
     const int64_t *slot_last = &s_ring[(n_items - 1) & 3][0];
     if ((n_items - 1) & 1) flush(std::integral_constant<int, 1>(), slot_last);

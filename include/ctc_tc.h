@@ -126,7 +126,7 @@ const char *ctc_tc_last_error(void);
  *                   1: never the persistent kernel; 2: the persistent kernel whenever it can run the
  *                   launch (f64 / f32, 16-byte-vector layouts, 16-byte stores of C, beta == 0, one
  *                   batch entry, K > 32);
- *   "stream_max_k"  largest K the automatic choice sends to the persistent kernel (default 512);
+ *   "stream_max_k"  largest K the automatic choice sends to the persistent kernel (default 128; fp32: at most 96);
  *   "stream_f64_dma" 1 (default): fp64 launches that qualify (even M and N, one stride per operand along
  *                   K) take the persistent kernel's LDS-DMA form; 0: its register-staged form.
  * No reference counterpart.
