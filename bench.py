@@ -198,7 +198,7 @@ def bench_contracted(args, world, rank, dev, backend):
     v = run_contracted(args.extent, world, rank, dev, backend, args.steps, args.warmup)
     if rank == 0:
         n = args.extent
-        print(json.dumps({
+        emit(({
             "metric": "achieved TFLOP/s per contraction (fp64, C[a,b,i,j]=A[a,e,i,m]*B[e,b,m,j])",
             "value": v["tflops"], "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": v["ms_per_step"],
@@ -212,7 +212,27 @@ def bench_contracted(args, world, rank, dev, backend):
         dist.destroy_process_group()
 
 
+def _claim_stdout():
+    """Rank 0 prints ONE JSON line on stdout.  Libraries underneath (RCCL prints a version banner when a
+    communicator is created) write to file descriptor 1 as well, so the descriptor is pointed at stderr
+    for the whole run and the line goes to a private copy of the original."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(keep, "w")
+
+
+RESULT = None  # the original stdout, claimed in main()
+
+
+def emit(obj):
+    RESULT.write(json.dumps(obj) + "\n")
+    RESULT.flush()
+
+
 def main():
+    global RESULT
+    RESULT = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -367,7 +387,7 @@ def main():
                           "oracle (OpenMP over the outermost free index, every CPU of this job's share); the "
                           "reference has no CPU contraction path" % (args.cpu_extent, args.cpu_extent, dt),
             }
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

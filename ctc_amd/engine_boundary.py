@@ -183,9 +183,14 @@ def _catalog_file(engine_root, tag, item_id):
 
 
 class Workflow:
-    """A workflow descriptor as the engine reads it (engine/src/ctc_workflow.cpp:38-144)."""
+    """A workflow descriptor as the engine reads it (engine/src/ctc_workflow.cpp:38-144), or one put
+    together step by step as a C++ host does with Workflow::addInput / addStep / addOutput
+    (engine/examples/c++/align_workflow.cpp:23-62)."""
 
-    def __init__(self, path):
+    def __init__(self, path=None):
+        if path is None:
+            self.id, self.inputs, self.steps, self.outputs = "", {}, [], {}
+            return
         root = ET.parse(path).getroot()
         self.id = root.attrib["id"]
         self.inputs = {p.attrib["name"]: dict(p.attrib) for p in root.find("inputs")}
@@ -204,7 +209,20 @@ class Workflow:
             self.outputs[p.attrib["name"]] = p.attrib["value"]
 
 
+    def add_step(self, step_id, plugin_id, inputs, outputs):
+        """inputs: (name, value) pairs; outputs: names."""
+        self.steps.append({"id": step_id, "plugin_id": plugin_id, "inputs": list(inputs), "outputs": list(outputs)})
+        return self
+
+
 def workflow_commands(workflow_id, params, workdir, engine_root=ENGINE_ROOT, org_dir="/", env=None):
+    """workflow_commands_of for a workflow of the catalog."""
+    root = os.path.abspath(engine_root)
+    wf = Workflow(_catalog_file(root + "/", "workflow", workflow_id))
+    return workflow_commands_of(wf, params, workdir, engine_root, org_dir, env)
+
+
+def workflow_commands_of(wf, params, workdir, engine_root=ENGINE_ROOT, org_dir="/", env=None):
     """What Engine::executeWorkflow does with these call parameters
     (engine/src/ctc_engine.cpp:186-311): returns (commands, moves).  `workdir` stands for the
     mkdtemp directory the engine changes into; `name.param` call parameters go to step `name`;
@@ -213,7 +231,6 @@ def workflow_commands(workflow_id, params, workdir, engine_root=ENGINE_ROOT, org
     root = os.path.abspath(engine_root)
     if not root.endswith("/"):
         root += "/"
-    wf = Workflow(_catalog_file(root, "workflow", workflow_id))
     sys_params = {"ENGINE_DIR": root}
     exec_params, step_params = {}, {st["id"]: {} for st in wf.steps}
     for name, value in params.items():

@@ -62,6 +62,69 @@ def best_offsets(batch, device="cuda:0"):
     return DeviceBatch(batch, device).run().results()
 
 
+def _consensus_key(text):
+    """The key the reference's consensus table deduplicates on: the 31-polynomial string hash in signed
+    32-bit arithmetic over signed bytes (apps/fastr/Consensus.cpp:83-94) pushed through the table's bit
+    mixer (apps/fastr/ConsensusHashTable.cpp:148-153).  Two strings with one key count as one consensus
+    (:225-237 compares the keys only)."""
+    h = 1
+    for c in text:
+        h = (31 * h + (c - 256 if c > 127 else c)) & 0xFFFFFFFF
+    h ^= (h >> 20) ^ (h >> 12)
+    h ^= (h >> 7) ^ (h >> 4)
+    return h
+
+
+def flatten_regions(regions, read_stride, reference_padding=0):
+    """Flattens realignment regions into the batch ctc_fastr_best_offsets takes, as clean_gpu_prep does
+    (apps/fastr/IndelRealigner.cpp:714-752).  Each region is a dict:
+        bin_reads   [(position, soft_clip, bases, phred)]  reads of the bin that are not scored
+        alt_reads   [(position, soft_clip, bases, phred)]  the reads that are scored, in order
+        candidates  [bases]                                 consensus strings in the order they were found
+    The bin starts at the FIRST read's position (apps/fastr/ReadBin.cpp:82-84), moved left by
+    `reference_padding` (not below 0) once the bin's reference was fetched (:99-107; the reference pads
+    by 30).  A read contributes its bases and qualities after the leading soft clip, which is what
+    AlignedRead::getUnclippedBases keeps (apps/fastr/AlignedRead.cpp:61-124).  Candidates whose table
+    keys collide are dropped after the first (see _consensus_key); the rest keep insertion order
+    (ConsensusHashTable.cpp:113-119)."""
+    enc = lambda b: b.encode() if isinstance(b, str) else bytes(b)  # noqa: E731
+    seq, quals, read_len, orig, n_consensus, alt_reads, ref_lens, ref = [], [], [], [], [], [], [], bytearray()
+    for region in regions:
+        reads = list(region["bin_reads"]) + list(region["alt_reads"])
+        if not reads:
+            raise ValueError("a region needs at least one read to have a start")
+        leftmost = max(reads[0][0] - reference_padding, 0) if reference_padding else reads[0][0]
+        alt_reads.append(len(region["alt_reads"]))
+        for position, clip, bases, phred in region["alt_reads"]:
+            b, q = enc(bases)[clip:], bytes(phred)[clip:]
+            if len(b) > read_stride:
+                raise ValueError("read of %d bases does not fit the stride %d" % (len(b), read_stride))
+            row = np.zeros(read_stride, np.uint8)
+            row[:len(b)] = np.frombuffer(b, np.uint8)
+            seq.append(row)
+            row = np.zeros(read_stride, np.uint8)
+            row[:len(q)] = np.frombuffer(q, np.uint8)
+            quals.append(row)
+            read_len.append(len(b))
+            orig.append(position - leftmost)
+        seen, kept = set(), 0
+        for c in region["candidates"]:
+            c = enc(c)
+            key = _consensus_key(c)
+            if key in seen:
+                continue
+            seen.add(key)
+            ref += c
+            ref_lens.append(len(c))
+            kept += 1
+        n_consensus.append(kept)
+    cat = lambda rows: np.concatenate(rows) if rows else np.zeros(0, np.uint8)  # noqa: E731
+    return {"ref": np.frombuffer(bytes(ref), np.uint8).copy(), "ref_lens": np.array(ref_lens, np.int32),
+            "n_consensus": np.array(n_consensus, np.int32), "alt_reads": np.array(alt_reads, np.int32),
+            "read_seq": cat(seq), "quals": cat(quals), "read_len": np.array(read_len, np.int32),
+            "original_alignment": np.array(orig, np.int32), "read_stride": int(read_stride)}
+
+
 # ---- pairwise alignment (apps/fastr/SWPairwiseAlignment.cpp) ----------------------------------
 DEFAULT_SW_WEIGHTS = (30.0, -10.0, -10.0, -2.0)  # apps/fastr/IndelRealigner.cpp:165-168
 _sw_bound = False

@@ -20,11 +20,17 @@ for f in ctc_catalog ctc_logger ctc_plugin ctc_sysconfig ctc_util ctc_workflow; 
     $CXX -c "$REF/engine/src/$f.cpp" -o "$OUT/obj/$f.o"
 done
 sed '230,276s/\bit\b/it_inner/g' "$REF/engine/src/ctc_engine.cpp" | $CXX -x c++ -c - -o "$OUT/obj/ctc_engine.o"
-for prog in execute_engine query_engine; do
+#   import_script, create_workflow : the reference's script importer (engine/src/import_script.cpp:50-97:
+#       inline `name := { commands }` definitions become plugins chained into one workflow) and its
+#       interactive workflow editor, compiled unmodified.
+#   align_workflow : engine/examples/c++/align_workflow.cpp, compiled unmodified (it builds a four-step
+#       workflow through the C++ API and dry-runs it, :64-73).
+for prog in execute_engine query_engine import_script create_workflow; do
     $CXX "$REF/engine/src/$prog.cpp" "$OUT"/obj/ctc_*.o -o "$OUT/$prog"
 done
+$CXX "$REF/engine/examples/c++/align_workflow.cpp" "$OUT"/obj/ctc_*.o -o "$OUT/align_workflow"
 rm -rf "$OUT/obj"
-echo "built $OUT/execute_engine $OUT/query_engine"
+echo "built $OUT/execute_engine $OUT/query_engine $OUT/import_script $OUT/create_workflow $OUT/align_workflow"
 
 #   libfastr_ref.so : the reference's CPU scoring path of apps/fastr (findBestOffset and
 #       mismatchQualitySumIgnoreCigar), compiled from the reference sources with the vendored

@@ -162,3 +162,63 @@ def pair_iter(batch):
             ref_off += L
             cons += 1
         read_off += batch["alt_reads"][t]
+
+
+def reference_regions(regions, stride):
+    """Builds every region out of the reference's own BamAlignment / AlignedRead / ReadBin / Consensus /
+    ConsensusHashTable objects, flattens them with the reference's getters in clean_gpu_prep's order
+    (apps/fastr/IndelRealigner.cpp:714-752) and scores every (consensus, read) pair with the reference's
+    findBestOffset (:857-880).  `regions`: list of dicts with
+        bin_reads   [(position, soft_clip, bases str, phred list)]   reads that only widen the bin
+        alt_reads   [(position, soft_clip, bases str, phred list)]   the reads that are scored
+        candidates  [str]                                             consensus strings, duplicates allowed
+    Returns the flattened batch (the layout ctc_fastr_best_offsets takes) plus best_index / best_score."""
+    L = ctypes.CDLL(REFERENCE_LIB)
+    L.fastr_ref_regions.restype = ctypes.c_int
+    L.fastr_ref_regions.argtypes = [ctypes.c_int] + [_vp] * 10 + [ctypes.c_int] + [_vp] * 11
+    n_bin, n_alt, pos, length, clip, n_cand, cand_len = [], [], [], [], [], [], []
+    bases, phred, cand = bytearray(), bytearray(), bytearray()
+    for r in regions:
+        reads = list(r["bin_reads"]) + list(r["alt_reads"])
+        n_bin.append(len(reads))
+        n_alt.append(len(r["alt_reads"]))
+        for p, c, b, q in reads:
+            pos.append(p)
+            length.append(len(b))
+            clip.append(c)
+            bases += b.encode()
+            phred += bytes(q)
+        n_cand.append(len(r["candidates"]))
+        for c in r["candidates"]:
+            cand_len.append(len(c))
+            cand += c.encode()
+    i32 = lambda v: np.ascontiguousarray(v, dtype=np.int32)  # noqa: E731
+    u8 = lambda v: np.frombuffer(bytes(v) + b"\0", dtype=np.uint8).copy()  # noqa: E731
+    n_bin, n_alt, pos, length, clip, n_cand, cand_len = map(i32, (n_bin, n_alt, pos, length, clip, n_cand, cand_len))
+    bases, phred, cand = u8(bases), u8(phred), u8(cand)
+    total_reads = int(n_alt.sum())
+    total_cons = int(n_cand.sum())
+    max_pairs = int((n_alt.astype(np.int64) * n_cand).sum())
+    read_seq = np.zeros(max(total_reads, 1) * stride, np.uint8)
+    quals = np.zeros(max(total_reads, 1) * stride, np.uint8)
+    read_len = np.zeros(max(total_reads, 1), np.int32)
+    orig = np.zeros(max(total_reads, 1), np.int32)
+    n_consensus = np.zeros(len(regions), np.int32)
+    alt_reads = np.zeros(len(regions), np.int32)
+    ref_lens = np.zeros(max(total_cons, 1), np.int32)
+    ref = np.zeros(max(int(cand_len.sum()), 1), np.uint8)
+    totals = np.zeros(4, np.int32)
+    best_index = np.zeros(max(max_pairs, 1), np.int32)
+    best_score = np.zeros(max(max_pairs, 1), np.int32)
+    d = lambda a: a.ctypes.data  # noqa: E731
+    rc = L.fastr_ref_regions(len(regions), d(n_bin), d(n_alt), d(pos), d(length), d(clip), d(bases), d(phred),
+                             d(n_cand), d(cand_len), d(cand), stride, d(read_seq), d(quals), d(read_len), d(orig),
+                             d(n_consensus), d(alt_reads), d(ref_lens), d(ref), d(totals), d(best_index),
+                             d(best_score))
+    if rc != 0:
+        raise RuntimeError("fastr_ref_regions: a read is longer than the stride")
+    t_reads, t_ref, t_score, t_cons = (int(x) for x in totals)
+    return {"ref": ref[:t_ref], "ref_lens": ref_lens[:t_cons], "n_consensus": n_consensus, "alt_reads": alt_reads,
+            "read_seq": read_seq[:t_reads * stride], "quals": quals[:t_reads * stride], "read_len": read_len[:t_reads],
+            "original_alignment": orig[:t_reads], "read_stride": stride,
+            "best_index": best_index[:t_score], "best_score": best_score[:t_score]}

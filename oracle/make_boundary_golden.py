@@ -58,9 +58,70 @@ def plugin_xml(p):
     return "\n".join(lines)
 
 
+REFERENCE_ROOT = "/root/reference/engine/test"   # the reference's own plugin / workflow repository
+ALIGN_EXAMPLE = os.path.join(ROOT, "oracle", "_ref", "align_workflow")
+
+# Dry runs of what the reference itself holds: its fastr plugin (engine/test/plugins/fastr/FastR.xml:1-23),
+# its bwa_pe_sam workflow (engine/test/workflows/bwa_pe_sam.xml) and its C++ example
+# (engine/examples/c++/align_workflow.cpp:23-73, compiled unmodified).  Only call parameters and the
+# command lines the reference engine logged are stored; the descriptors stay in the reference tree.
+REFERENCE_CALLS = [
+    {"kind": "plugin", "id": "fastr",
+     "params": {"input_bam": "/d/in.bam", "input_interval": "/d/in.intervals", "ref_file": "/d/hg19.fa",
+                "output_bam": "/d/out.bam", "use_sw": "true"}},
+    {"kind": "plugin", "id": "fastr",
+     "params": {"input_bam": "/d/in.bam", "input_interval": "/d/in.intervals", "ref_file": "/d/hg19.fa",
+                "output_bam": "/d/out.bam", "num_threads": "16"}},
+    {"kind": "workflow", "id": "bwa_pe_sam",
+     "params": {"input-read1": "/d/r1.fq", "input-read2": "/d/r2.fq", "ref_genome": "/d/hg19", "output_sam": "/d/out.sam"}},
+    {"kind": "example", "id": "align_workflow", "params": {}},
+]
+
+
+def _parse_log(log, root):
+    """(workdir, commands, moves) from the engine's dry-run log; the mkdtemp directory reads <WORK>."""
+    work = re.findall(r"Changing working directory to (\S+)", log)
+    workdir = work[0] if work else ""
+    norm = lambda t: t.replace(workdir, "<WORK>").replace(root, "<ROOT>") if workdir else t.replace(root, "<ROOT>")  # noqa: E731
+    commands = [norm(c) for c in re.findall(r"Executing: (.*)", log)]
+    moves = [[norm(a), norm(b)] for a, b in re.findall(r"Moving file from (\S+) to (\S+)", log)]
+    return commands, moves
+
+
+def reference_fixtures():
+    """Runs the reference engine on a scratch copy of the reference's repository (the engine creates its
+    workspace inside the repository it is given, and the reference tree is read-only)."""
+    if not os.path.isdir(REFERENCE_ROOT):
+        return None
+    out = []
+    tmp = tempfile.mkdtemp()
+    try:
+        root = os.path.join(tmp, "oge")
+        shutil.copytree(REFERENCE_ROOT, root)
+        for call in REFERENCE_CALLS:
+            if call["kind"] == "example":
+                argv = [ALIGN_EXAMPLE, root]
+            else:
+                argv = [ENGINE, root, "--test", call["kind"], call["id"]]
+                for k, v in call["params"].items():
+                    argv += ["--" + k, v]
+            log = subprocess.run(argv, capture_output=True, text=True, cwd=root).stdout
+            commands, moves = _parse_log(log, root)
+            out.append(dict(call, commands=commands, moves=moves))
+    finally:
+        shutil.rmtree(tmp)
+    return out
+
+
 def main():
     if not os.path.exists(ENGINE):
         sys.exit("build the reference engine first: bash oracle/build_ref.sh")
+    ref = reference_fixtures()
+    if ref is not None:
+        path = os.path.join(ROOT, "tests", "golden", "boundary_reference_golden.json")
+        with open(path, "w") as f:
+            json.dump(ref, f, indent=1)
+        print("wrote", path, len(ref), "calls")
     out = []
     tmp = tempfile.mkdtemp()
     try:

@@ -260,3 +260,141 @@ def test_permute_then_contract_workflow_through_the_unchanged_engine(tmp_path, o
     want = oracle.contract("adc,db->abc", ext, A, B)   # same result as contracting the unpermuted A
     assert got.shape == want.shape
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+# ---- what the reference itself holds: its fastr plugin, its bwa_pe_sam workflow, its C++ example ----------
+REFERENCE_OGE = "/root/reference/engine/test"
+ALIGN_EXAMPLE = os.path.join(ROOT, "oracle", "_ref", "align_workflow")
+IMPORT_SCRIPT = os.path.join(ROOT, "oracle", "_ref", "import_script")
+
+
+def _reference_golden():
+    with open(os.path.join(ROOT, "tests", "golden", "boundary_reference_golden.json")) as f:
+        return json.load(f)
+
+
+def _align_example_workflow():
+    """The workflow engine/examples/c++/align_workflow.cpp:23-62 builds through the C++ API."""
+    wf = eb.Workflow()
+    wf.inputs = {"in_read1": {}, "in_read2": {}, "in_genome": {}}
+    wf.add_step("aln1", "bwa_aln", [("input_read", "$in_read1"), ("ref_genome", "$in_genome")], ["output_sai"])
+    wf.add_step("aln2", "bwa_aln", [("input_read", "$in_read2"), ("ref_genome", "$in_genome")], ["output_sai"])
+    wf.add_step("tosam", "bwa_sampe", [("input_read1", "$in_read1"), ("input_read2", "$in_read2"), ("ref_genome", "$in_genome"),
+                                       ("input_sai1", "$aln1.output_sai"), ("input_sai2", "$aln2.output_sai")], ["output_sam"])
+    wf.add_step("tobam", "sam_sorted_bam", [("input_sam", "$tosam.output_sam")], ["output_bam"])
+    wf.outputs = {"output": "$tobam.output_bam"}
+    params = {"in_read1": "/path/to/in1.fast1", "in_read2": "/path/to/in1.fast2", "in_genome": "/path/to/genome.fasta",
+              "output": "/path/to/results.bam"}
+    return wf, params
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_OGE), reason="needs the reference's plugin repository (/root/reference)")
+def test_mirror_reproduces_the_reference_held_fixtures_byte_for_byte():
+    """The command lines the reference engine logged for ITS OWN descriptors (tests/golden/
+    boundary_reference_golden.json, made by oracle/make_boundary_golden.py) against the host-side mirror
+    reading the same descriptors: equal but for the mkdtemp directory, which reads <WORK>."""
+    for c in _reference_golden():
+        if c["kind"] == "plugin":
+            got = ['"%s"' % x for x in eb.plugin_commands(c["id"], c["params"], engine_root=REFERENCE_OGE)]
+            assert got == c["commands"], c["id"]
+            continue
+        if c["kind"] == "workflow":
+            cmds, moves = eb.workflow_commands(c["id"], c["params"], "<WORK>", engine_root=REFERENCE_OGE)
+        else:
+            wf, params = _align_example_workflow()
+            cmds, moves = eb.workflow_commands_of(wf, params, "<WORK>", engine_root=REFERENCE_OGE)
+        assert cmds == c["commands"], c["id"]
+        assert [list(m) for m in moves] == c["moves"], c["id"]
+
+
+@pytest.mark.skipif(not (os.path.isdir(REFERENCE_OGE) and os.path.exists(ALIGN_EXAMPLE) and os.path.exists(ENGINE)),
+                    reason="needs /root/reference and oracle/_ref (oracle/build_ref.sh)")
+def test_reference_engine_still_logs_the_committed_fixtures(tmp_path):
+    """Live: the reference engine and the reference's example, compiled here unmodified, on a scratch copy
+    of the reference's repository, against the committed fixture."""
+    import shutil
+    root = str(tmp_path / "oge")
+    shutil.copytree(REFERENCE_OGE, root)
+    for c in _reference_golden():
+        if c["kind"] == "example":
+            argv = [ALIGN_EXAMPLE, root]
+        else:
+            argv = [ENGINE, root, "--test", c["kind"], c["id"]]
+            for k, v in c["params"].items():
+                argv += ["--" + k, v]
+        log = subprocess.run(argv, capture_output=True, text=True, cwd=root).stdout
+        work = re.findall(r"Changing working directory to (\S+)", log)[0]
+        cmds = [x.replace(work, "<WORK>").replace(root, "<ROOT>") for x in re.findall(r"Executing: (.*)", log)]
+        moves = [[a.replace(work, "<WORK>"), b] for a, b in re.findall(r"Moving file from (\S+) to (\S+)", log)]
+        assert cmds == c["commands"] and moves == c["moves"], c["id"]
+
+
+def _imported_script(tool, b_file, ext):
+    extents = ",".join("%s=%d" % kv for kv in ext.items())
+    return "\n".join([
+        "# two inline plugins chained by the reference's script importer",
+        "WORKFLOW_ID=imported_permute_contract",
+        'WORKFLOW_NAME="permute A, then contract, from a script"',
+        "WORKFLOW_VERSION=0.1",
+        "SUITE_ID=imported",
+        "TOOL=" + tool,
+        "B_FILE=" + b_file,
+        "permute_a := {",
+        "    $TOOL --permute adc=acd --extents " + extents + " --dtype f64 --a $input --out $output",
+        "}",
+        "contract_ab := {",
+        "    $TOOL --spec acd,db=abc --extents " + extents + " --dtype f64 --a $input --b $B_FILE --out $output",
+        "}",
+        ""])
+
+
+@pytest.mark.skipif(not (os.path.exists(IMPORT_SCRIPT) and os.path.exists(ENGINE)), reason="needs oracle/_ref (oracle/build_ref.sh)")
+def test_import_script_builds_the_permute_contract_workflow(tmp_path):
+    """The reference's import_script (engine/src/import_script.cpp:50-97), compiled unmodified, turns a
+    script with two inline definitions into two plugins and a workflow inside a scratch copy of the
+    contraction repository; the unchanged engine then dry-runs it: each step's $input is the previous
+    step's $output, the first $input and the last $output are the workflow's."""
+    import shutil
+    root = str(tmp_path / "oge")
+    shutil.copytree(eb.ENGINE_ROOT, root, ignore=shutil.ignore_patterns("workspace"))
+    ext = dict(a=8, b=6, c=5, d=7)
+    script = tmp_path / "script.txt"
+    script.write_text(_imported_script(TOOL, "/d/B.bin", ext))
+    run = subprocess.run([IMPORT_SCRIPT, root, str(script)], capture_output=True, text=True, cwd=str(tmp_path))
+    assert os.path.exists(os.path.join(root, "workflows", "imported_permute_contract.xml")), run.stdout + run.stderr
+    log = subprocess.run([ENGINE, root, "--test", "workflow", "imported_permute_contract", "--input", "/d/A.bin", "--output",
+                          "/d/C.bin"], capture_output=True, text=True, cwd=str(tmp_path)).stdout
+    work = re.findall(r"Changing working directory to (\S+)", log)[0]
+    cmds = re.findall(r"Executing: (.*)", log)
+    extents = "a=8,b=6,c=5,d=7"
+    assert [c.strip() for c in cmds] == [
+        "%s --permute adc=acd --extents %s --dtype f64 --a /d/A.bin --out %s/permute_a-permute_a-output.tmp" % (TOOL, extents, work),
+        "%s --spec acd,db=abc --extents %s --dtype f64 --a permute_a-permute_a-output.tmp --b /d/B.bin --out "
+        "%s/contract_ab-contract_ab-output.tmp" % (TOOL, extents, work)]
+    assert re.findall(r"Moving file from (\S+) to (\S+)", log) == [("contract_ab-contract_ab-output.tmp", "/d/C.bin")]
+
+
+@pytest.mark.gpu
+def test_imported_script_workflow_runs_on_the_gpu_through_the_unchanged_engine(tmp_path, oracle):
+    """The same imported workflow executed for real: A stored as [a,d,c] is permuted and contracted by the
+    two script-defined plugins; the file the engine moves into place must equal the oracle's result."""
+    import shutil
+    if not (os.path.exists(IMPORT_SCRIPT) and os.path.exists(ENGINE)):
+        pytest.fail("oracle/_ref/import_script or execute_engine missing: run oracle/build_ref.sh where /root/reference exists")
+    root = str(tmp_path / "oge")
+    shutil.copytree(eb.ENGINE_ROOT, root, ignore=shutil.ignore_patterns("workspace"))
+    ext = dict(a=32, b=48, c=16, d=24)
+    A = oracle.fill(ext["a"] * ext["d"] * ext["c"], 0xC7C0A)
+    B = oracle.fill(ext["d"] * ext["b"], 0xC7C0B)
+    A.tofile(tmp_path / "A.bin")
+    B.tofile(tmp_path / "B.bin")
+    script = tmp_path / "script.txt"
+    script.write_text(_imported_script(TOOL, str(tmp_path / "B.bin"), ext))
+    subprocess.run([IMPORT_SCRIPT, root, str(script)], capture_output=True, text=True, cwd=str(tmp_path))
+    run = subprocess.run([ENGINE, root, "workflow", "imported_permute_contract", "--input", str(tmp_path / "A.bin"), "--output",
+                          str(tmp_path / "C.bin")], capture_output=True, text=True, cwd=str(tmp_path))
+    assert os.path.exists(tmp_path / "C.bin"), run.stdout + run.stderr
+    got = np.fromfile(tmp_path / "C.bin", dtype=np.float64)
+    want = oracle.contract("adc,db->abc", ext, A, B)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
