@@ -126,7 +126,7 @@ void release_tables(std::map<int, DeviceTables> &tables)
     tables.clear();
 }
 
-// Offset tables of mode permutations, cached per (device, extents, permutation) and bounded: beyond
+// Offset tables of mode permutations, cached per (device, element size, extents, permutation) and bounded: beyond
 // kPermCacheMax entries the least recently used one is freed (hipFree waits for the device, so a
 // kernel that still reads the evicted tables finishes first; a caller cycling through more shapes
 // than that pays this wait, everyone else never reaches it).
@@ -136,12 +136,12 @@ struct PermCacheEntry {
     std::list<std::string>::iterator lru;
 };
 std::mutex g_perm_mu;
-std::map<std::string, PermCacheEntry> g_perm_cache;  // key: device|extents|perm
+std::map<std::string, PermCacheEntry> g_perm_cache;  // key: device|element size|extents|perm
 std::list<std::string> g_perm_lru;                   // most recently used first
 
-int get_permute_tables(int device, int rank, const int64_t *extents, const int *perm, PermuteTables &out)
+int get_permute_tables(int device, int rank, const int64_t *extents, const int *perm, int elem_size, PermuteTables &out)
 {
-    std::string key = std::to_string(device) + "|";
+    std::string key = std::to_string(device) + "|" + std::to_string(elem_size) + "|";
     for (int i = 0; i < rank; ++i) key += std::to_string(extents[i]) + ",";
     key += "|";
     for (int i = 0; i < rank; ++i) key += std::to_string(perm[i]) + ",";
@@ -159,7 +159,7 @@ int get_permute_tables(int device, int rank, const int64_t *extents, const int *
         g_perm_lru.pop_back();
     }
     ctc::PermutePlan pp;
-    std::string e = ctc::plan_permute(rank, extents, perm, pp);
+    std::string e = ctc::plan_permute(rank, extents, perm, elem_size, pp);
     if (!e.empty()) return fail(CTC_TC_EINVAL, e);
     const std::vector<int64_t> *src[6] = {&pp.in_x, &pp.out_x, &pp.in_y, &pp.out_y, &pp.in_o, &pp.out_o};
     size_t total = 0, start[6];
@@ -191,10 +191,9 @@ int get_permute_tables(int device, int rank, const int64_t *extents, const int *
     // side (the next o lies right behind the y run in the output, or behind the x run in the
     // input); otherwise one, which measures 9 % faster (128^4 fp32 abdc <- abcd: 5.2 -> 5.7 TB/s).
     t.params.o_per_block = (pp.O > 1 && (pp.out_o[1] == pp.Y || pp.in_o[1] == pp.X)) ? 4 : 1;
-    for (int i = 0; i < 3; ++i) {
-        const int64_t v = 8 >> i;  // elements per 16 bytes for 2-, 4-, 8-byte elements
-        t.params.vec_ok[i] = (pp.fast_in_extent % v == 0 && pp.fast_out_extent % v == 0) ? 1 : 0;
-    }
+    t.params.vec_mode = pp.vec_mode;
+    t.params.in_run = pp.in_run;
+    t.params.out_run = pp.out_run;
     g_perm_lru.push_front(key);
     g_perm_cache[key] = PermCacheEntry{t, g_perm_lru.begin()};
     out = t;
@@ -646,9 +645,10 @@ int ctc_tc_plan_prepare(ctc_tc_plan *plan)
         if (rc) return rc;
         TransposeShapes ts = transpose_shapes(p);
         PermuteTables unused;
-        rc = get_permute_tables(device, (int)ts.ea.size(), ts.ea.data(), p.perm_a.data(), unused);
-        if (rc == CTC_TC_OK) rc = get_permute_tables(device, (int)ts.eb.size(), ts.eb.data(), p.perm_b.data(), unused);
-        if (rc == CTC_TC_OK) rc = get_permute_tables(device, (int)ts.eg.size(), ts.eg.data(), p.perm_c.data(), unused);
+        const int es = (int)ctc::dtype_size(p.dtype);
+        rc = get_permute_tables(device, (int)ts.ea.size(), ts.ea.data(), p.perm_a.data(), es, unused);
+        if (rc == CTC_TC_OK) rc = get_permute_tables(device, (int)ts.eb.size(), ts.eb.data(), p.perm_b.data(), es, unused);
+        if (rc == CTC_TC_OK) rc = get_permute_tables(device, (int)ts.eg.size(), ts.eg.data(), p.perm_c.data(), es, unused);
         if (rc) return rc;
         const size_t ttgt = (size_t)ctc_tc_ttgt_workspace_bytes(plan);
         if (ttgt > bytes) bytes = ttgt;
@@ -731,7 +731,8 @@ int ctc_tc_permute(const void *in, void *out, int rank, const int64_t *extents_i
     int rc = current_device(device);
     if (rc) return rc;
     PermuteTables t;
-    rc = get_permute_tables(device, rank, extents_in, perm, t);
+    if (elem_size != 2 && elem_size != 4 && elem_size != 8) return fail(CTC_TC_EINVAL, "element size must be 2, 4 or 8 bytes");
+    rc = get_permute_tables(device, rank, extents_in, perm, elem_size, t);
     if (rc) return rc;
     ctc::PermuteParams p = t.params;
     p.in = in;

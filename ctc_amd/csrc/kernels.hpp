@@ -147,8 +147,11 @@ struct PermuteParams {
     const int64_t *in_o = nullptr, *out_o = nullptr;
     int64_t X = 1, Y = 1, O = 1;
     int same_fast = 0;  // 1: input and output share their fastest mode (row copy)
-    int vec_ok[3] = {0, 0, 0};  // 16-byte vectors legal for 2-, 4-, 8-byte elements (index log2(size)-1)
+    int vec_mode = 0;  // for the element size the tables were built for: 2 vectors on both sides, 1 vectors with
+                       // element tails (one mode on a ragged side), 0 element accesses (see PermutePlan)
     int o_per_block = 4;        // consecutive o values one workgroup of the vector kernel walks
+    int64_t in_run = 1, out_run = 1;  // contiguous elements of the input along x / of the output along y
+    int nt_loads = 0, nt_stores = 0;  // streaming hints, set by launch_permute
 };
 hipError_t launch_permute(int elem_size, const PermuteParams &p, hipStream_t stream);
 

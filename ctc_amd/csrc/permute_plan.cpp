@@ -30,10 +30,12 @@ void offsets(const std::vector<int> &modes, const std::vector<int64_t> &ext,
 
 }  // namespace
 
-std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, PermutePlan &pl)
+std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, int elem_size, PermutePlan &pl)
 {
     pl = PermutePlan();
     if (rank <= 0 || rank > 32) return "bad rank";
+    if (elem_size != 2 && elem_size != 4 && elem_size != 8) return "element size must be 2, 4 or 8 bytes";
+    const int64_t V = 16 / elem_size;  // elements per 16-byte vector
     std::vector<int> seen(rank, 0);
     int64_t total = 1;
     for (int p = 0; p < rank; ++p) {
@@ -95,30 +97,80 @@ std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, P
     std::vector<int> xm, ym, om;
     if (r <= 1 || q[r - 1] == r - 1) {
         pl.same_fast = true;
+        pl.vec_mode = (r >= 1 && ext[r - 1] % V == 0) ? 2 : 0;
         if (r >= 1) xm.push_back(r - 1);
         for (int p = r - 2; p >= 0; --p) om.push_back(q[p]);  // fastest first, output order
     } else {
-        const int fi = r - 1;
+        // Each side starts from its fastest mode.  A side whose fastest extent is a multiple of V may fuse
+        // further modes (a vector never straddles two runs of the fastest mode): first up to a volume of
+        // 64, then - below - for as long as that trims the part of the last patch that hangs over the
+        // edge.  A side whose fastest extent is NOT a multiple of V keeps that one mode when it is long
+        // enough (>= 32 elements of 4 or 8 bytes): the kernel then moves whole vectors at element-aligned
+        // addresses and finishes each run with single elements.  Shorter odd extents fuse as before and
+        // go through the element kernel.
+        const int fi = r - 1, fo = q[r - 1];
+        const auto side_mode = [&](int64_t e) { return e % V == 0 ? 2 : (elem_size >= 4 && e >= 32) ? 1 : 0; };
+        const int mode_x = side_mode(ext[fi]), mode_y = side_mode(ext[fo]);
+        pl.vec_mode = std::min(mode_x, mode_y);
+        const bool fuse_x = pl.vec_mode == 0 || mode_x == 2, fuse_y = pl.vec_mode == 0 || mode_y == 2;
+        const int64_t tile = pl.vec_mode == 0 ? 64 : (elem_size >= 4 ? 32 : 16) * V;  // the larger patch of the vector kernel
         std::vector<int> used(r, 0);
-        int64_t vol = 1;
-        for (int p = r - 1; p >= 0 && vol < 64; --p) {
+        int64_t vol_y = 1, vol_x = 1;
+        for (int p = r - 1; p >= 0 && vol_y < 64; --p) {
             if (q[p] == fi) break;
             ym.push_back(q[p]);
             used[q[p]] = 1;
-            vol *= ext[q[p]];
+            vol_y *= ext[q[p]];
+            if (!fuse_y) break;
         }
-        vol = 1;
-        for (int i = r - 1; i >= 0 && vol < 64; --i) {
+        for (int i = r - 1; i >= 0 && vol_x < 64; --i) {
             if (used[i]) break;
             xm.push_back(i);
             used[i] = 1;
-            vol *= ext[i];
+            vol_x *= ext[i];
+            if (!fuse_x) break;
+        }
+        // Patches are tile x tile: an index of 80 fills 62 % of its two patches.  Take in further unused
+        // modes (next in the side's own order, so that runs stay as long as they can) while more than 3 %
+        // of a side's patches hang over the edge; the tables stay small (at most 64 K entries a side).
+        const auto waste = [&](int64_t n) { return (double)((n + tile - 1) / tile * tile) / (double)n; };
+        constexpr int64_t kMaxSide = 65536;
+        for (bool changed = true; changed;) {
+            changed = false;
+            if (fuse_x && waste(vol_x) > 1.03)
+                for (int i = r - 1; i >= 0; --i)
+                    if (!used[i] && vol_x * ext[i] <= kMaxSide) {
+                        xm.push_back(i);
+                        used[i] = 1;
+                        vol_x *= ext[i];
+                        changed = true;
+                        break;
+                    }
+            if (fuse_y && waste(vol_y) > 1.03)
+                for (int p = r - 1; p >= 0; --p)
+                    if (!used[q[p]] && vol_y * ext[q[p]] <= kMaxSide) {
+                        ym.push_back(q[p]);
+                        used[q[p]] = 1;
+                        vol_y *= ext[q[p]];
+                        changed = true;
+                        break;
+                    }
         }
         // fastest first in output order: consecutive o values (one workgroup walks a few) extend the
         // contiguous runs of the stores; ordering them by the input instead measured 5 % slower
         for (int p = r - 1; p >= 0; --p)
             if (!used[q[p]]) om.push_back(q[p]);
     }
+    const auto run = [&](const std::vector<int> &modes, const std::vector<int64_t> &stride) {
+        int64_t n = 1;
+        for (int m : modes) {
+            if (stride[m] != n) break;
+            n *= ext[m];
+        }
+        return n;
+    };
+    pl.in_run = run(xm, si);
+    pl.out_run = run(pl.same_fast ? xm : ym, so);
     offsets(xm, ext, si, pl.in_x, pl.X);
     offsets(xm, ext, so, pl.out_x, pl.X);
     offsets(ym, ext, si, pl.in_y, pl.Y);
