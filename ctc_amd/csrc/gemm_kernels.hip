@@ -92,6 +92,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
 #endif
     const int wm0 = (wave / WN) * (TM * 16);
     const int wn0 = (wave % WN) * (TN * 16);
+#ifdef CTC_CLOCK  // diagnostic build: shader clock while this workgroup runs = core-clock ticks / 100 MHz ticks
+    const unsigned long long ck_core0 = __builtin_readcyclecounter(), ck_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // Block -> tile.  Blocks b and b+8 share an XCD (and its L2): give each XCD a
     // contiguous run of tile ids, then walk tiles in groups of `group` tile rows so
@@ -389,6 +392,12 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
         if (beta == (T)0) store_rows(std::false_type());
         else store_rows(std::true_type());
     }
+#ifdef CTC_CLOCK
+    if (t == 0 && blockIdx.y == 0 && (blockIdx.x == 700 || blockIdx.x == 2500 || blockIdx.x == 4500)) {
+        const unsigned long long dc = __builtin_readcyclecounter() - ck_core0, dr = __builtin_amdgcn_s_memrealtime() - ck_real0;
+        printf("[clock] block %d: %llu core ticks in %llu x 10 ns -> %.3f GHz\n", (int)blockIdx.x, dc, dr, (double)dc / (10.0 * (double)dr));
+    }
+#endif
 #ifdef CTC_STAMPS
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -23,7 +23,9 @@
 #include "gemm_device.hpp"
 #include "kernels.hpp"
 
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 namespace ctc {
@@ -32,10 +34,30 @@ namespace {
 
 using namespace gemm_detail;
 
-constexpr int kBM = 128, kBN = 64, kBK = 32, kStages = 3;
-constexpr int kABytes = kBM * kBK * 8, kBBytes = kBN * kBK * 8, kStageBytes = kABytes + kBBytes;
-constexpr int kRingEntries = 2 * (kBM + kBN);  // A rows, B columns, C rows, C columns
-constexpr int kRingSlots = 4;
+constexpr int kBM = 128, kBN = 64, kStages = 3;
+// Two geometries.  K-tile 32: one workgroup per CU (144 KB of operand stages), every layout.  K-tile 16:
+// TWO workgroups per CU (72 KB of stages each, at most 128 + 128 registers a lane), so that a second wave
+// on every SIMD issues MFMAs while the first waits for a barrier, a DMA or an issue slot.
+template <int BK> struct Geom {
+    static constexpr int kABytes = kBM * BK * 8, kBBytes = kBN * BK * 8, kStageBytes = kABytes + kBBytes;
+    static constexpr bool kTwoPerCu = (BK == 16);
+    // Offset ring, in table entries.  An item's A rows and B columns are read once, when the loader moves
+    // on to the item; its C rows and C columns while the NEXT item is multiplied.
+    //   K-tile 32: four slots of [A rows | B columns | C rows | C columns], item it in slot it & 3,
+    //              fetched during the first K-tile of item it - 2;
+    //   K-tile 16: ONE slot of [A rows | B columns] and four of [C rows | C columns], fetched during the
+    //              last K-tile of item it - 2 (behind its barrier: every wave has moved its loader on).
+    static constexpr int kAbEntries = kBM + kBN, kCEntries = kBM + kBN;
+    static constexpr int kRingEntries = kTwoPerCu ? kAbEntries + 4 * kCEntries : 4 * (kAbEntries + kCEntries);
+    // entry index of the [A rows | B columns] / [C rows | C columns] run of item it
+    __device__ static __forceinline__ int ab_entry(int it) { return kTwoPerCu ? 0 : (it & 3) * (kAbEntries + kCEntries); }
+    __device__ static __forceinline__ int c_entry(int it)
+    {
+        return kTwoPerCu ? kAbEntries + (it & 3) * kCEntries : (it & 3) * (kAbEntries + kCEntries) + kAbEntries;
+    }
+    // K-tiles of an item that carry the previous item's stores (K >= 64: at least that many K-tiles)
+    static constexpr int kStoreTiles = 64 / BK;
+};
 
 __device__ __forceinline__ void dma16(const void *src, unsigned char *lds_wave_base)
 {
@@ -86,9 +108,10 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 // Address arithmetic is kept off the vector ALU (a wave that feeds the matrix pipe has about sixteen
 // issue slots per MFMA): per item a lane keeps byte POINTERS to what it fetches at k = 0, and a DMA adds
 // a wave-uniform byte offset for the K-tile (and, outer-major, for the line) to one of them.
-template <int LAY, int BR> struct DmaStager {
+template <int LAY, int BR, int BK> struct DmaStager {
     static constexpr bool KMAJ = (LAY != kLayOuterVec);
-    static constexpr int NI = BR * kBK * 8 / 1024 / 4;
+    static_assert(!KMAJ || BK == 32, "the K-major image is laid out for rows of 32 contracted elements");
+    static constexpr int NI = BR * BK * 8 / 1024 / 4;
     static constexpr int NROW = KMAJ ? NI : (BR == 128 ? 2 : 1);  // distinct rows among the NI fetches
     const char *ptr[NI];   // what instruction i fetches at k0 = 0
     int64_t rowoff[NROW];  // as read from the ring; turned into ptr[] by finish_rows
@@ -177,23 +200,26 @@ template <int LAY, int BR> struct FragAddr {
     template <int b, int kk> static constexpr int imm() { return KMAJ ? b * 16 * 256 : 128 * b + kk * 4 * BR * 8; }
 };
 
-template <int LA, int LB>
-__global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParams p)
+template <int LA, int LB, int BK>
+__global__ void __launch_bounds__(256, Geom<BK>::kTwoPerCu ? 2 : 1) gemm_stream_f64_kernel(const GemmParams p)
 {
-    constexpr int BM = kBM, BN = kBN, BK = kBK, WN = 2;
+    typedef Geom<BK> G_;
+    constexpr int BM = kBM, BN = kBN, WN = 2;
+    constexpr int kABytes = G_::kABytes, kStageBytes = G_::kStageBytes;
+    constexpr bool TWO = G_::kTwoPerCu;
     constexpr int TM = 4, TN = 2, NMFMA = TM * TN, KSTEPS = BK / 4, NIDX = NMFMA * KSTEPS;
     typedef Traits<double> Tr;
     typedef Tr::acc_t acc_t;
-    typedef DmaStager<LA, BM> SA;
-    typedef DmaStager<LB, BN> SB;
+    typedef DmaStager<LA, BM, BK> SA;
+    typedef DmaStager<LB, BN, BK> SB;
     constexpr int NDMA = SA::NI + SB::NI;            // operand DMAs per wave per K-tile
-    constexpr int STORE_TILES = 2;                   // K-tiles of an item that carry the previous item's stores
+    constexpr int STORE_TILES = G_::kStoreTiles;     // K-tiles of an item that carry the previous item's stores
     // the DMAs of a K-tile are all issued before the barrier that ends it
     constexpr int DMA_FIRST = 3, DMA_STEP = 4;
     static_assert(DMA_FIRST + DMA_STEP * (NDMA - 1) < (KSTEPS - 1) * NMFMA, "DMA schedule");
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes];
-    __shared__ __attribute__((aligned(16))) int64_t s_ring[kRingSlots][kRingEntries];
+    __shared__ __attribute__((aligned(16))) int64_t s_ring[G_::kRingEntries];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -205,6 +231,9 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
 
     const int G = (int)gridDim.x;
     const int bid = (int)blockIdx.x;
+#ifdef CTC_SX_CLOCK  // diagnostic build: shader clock during the kernel = core-clock ticks / 100 MHz ticks
+    const unsigned long long ck_core0 = __builtin_readcyclecounter(), ck_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int wslot = (G & 7) == 0 ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
     const int64_t tiles = (int64_t)p.nbm * p.nbn;
     if (wslot >= tiles) return;
@@ -255,8 +284,8 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
         // a column run is half an instruction long: only its lower 32 lanes take part
         int64_t g = first + 2 * (rows ? lane : (lane & 31));
         if (g > lim - 2) g = lim - 2;  // M and N are even here, so a pair never straddles the end
-        const int dst = (wave >> 1) * (BM + BN) + (rows ? 0 : BM);
-        if (rows || lane < 32) dma16(tab + g, reinterpret_cast<unsigned char *>(&s_ring[it & 3][dst]));
+        const int dst = (wave < 2 ? G_::ab_entry(it) : G_::c_entry(it)) + (rows ? 0 : BM);
+        if (rows || lane < 32) dma16(tab + g, reinterpret_cast<unsigned char *>(&s_ring[dst]));
         m_lim_new = (int)(p.M - m0 < BM ? p.M - m0 : BM);
         n_lim_new = (int)(p.N - n0 < BN ? p.N - n0 : BN);
     };
@@ -275,17 +304,26 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
     // ---- prologue
     ring_fetch(0);
     int m_lim_0 = m_lim_new, n_lim_0 = n_lim_new, m_lim_1 = 0, n_lim_1 = 0;
-    if (n_items > 1) {
+    if (!TWO && n_items > 1) {
         ring_fetch(1);
         m_lim_1 = m_lim_new;
         n_lim_1 = n_lim_new;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    sa.load_rows(&s_ring[0][0]);
-    sb.load_rows(&s_ring[0][BM]);
+    sa.load_rows(&s_ring[G_::ab_entry(0)]);
+    sb.load_rows(&s_ring[G_::ab_entry(0) + BM]);
     sa.finish_rows(A, false);
     sb.finish_rows(B, false);
+    if (TWO) {
+        // the one [A rows | B columns] slot has been read by every wave: item 1 may take it
+        __syncthreads();
+        if (n_items > 1) {
+            ring_fetch(1);
+            m_lim_1 = m_lim_new;
+            n_lim_1 = n_lim_new;
+        }
+    }
     auto issue_tile = [&](int kt, unsigned char *stage) {
         const int k0 = kt * BK;
         static_for<0, SA::NI>([&](auto i_t) {
@@ -301,7 +339,7 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
     __syncthreads();
 
     double fa[2][TM], fb[2][TN];
-    const unsigned smem_lds = lds_addr(smem), ring_lds = lds_addr(&s_ring[0][0]);
+    const unsigned smem_lds = lds_addr(smem), ring_lds = lds_addr(&s_ring[0]);
     // fragments of k-step KK of the stage at LDS address `stage` into slot S; asynchronous (frags_wait)
     auto read_frags = [&](auto slot_t, auto kk_t, unsigned stage) {
         constexpr int S = decltype(slot_t)::value, KK = decltype(kk_t)::value;
@@ -333,6 +371,14 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
     constexpr int NSTORE = TM * 4 * TN;  // per wave and item
     constexpr int SPT = NSTORE / STORE_TILES, SPACING = NIDX / SPT;
     static_assert(NSTORE % STORE_TILES == 0 && NIDX % SPT == 0 && SPACING >= 2, "store schedule");
+    // stores of a store tile that are issued before the tile's wait for its operands: in a tile whose stores
+    // are unconditional (FULL) they are known to sit in the in-order memory counter behind the DMAs the wait
+    // is for, so the wait may leave them outstanding as well instead of draining this tile's first DMAs
+#ifdef CTC_SX_STORES_AHEAD
+    constexpr int STORES_AHEAD = CTC_SX_STORES_AHEAD;
+#else
+    constexpr int STORES_AHEAD = ((KSTEPS - 1) * NMFMA - (SPACING > 2 ? 2 : 1) + SPACING - 1) / SPACING;
+#endif
     char *cptr[TN];                      // C + column offset of this lane's column in block j, in bytes
     int64_t cvoff[TN];
     int64_t rvoff[2] = {0, 0};           // row offsets: the row being stored and the next one (in flight)
@@ -346,12 +392,12 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
         constexpr int R = decltype(r_t)::value;
         lds_read64<8 * (16 * (R / 4) + 4 * (R % 4))>(rvoff[R & 1], row_lds);
     };
-    // slot: LDS address of the previous item's ring slot
+    // slot: LDS address of the previous item's [C rows | C columns] run
     auto load_cols = [&](unsigned slot) {
         static_assert(TN == 2, "two column offsets per lane");
-        lds_read64<8 * (BM + BN + BM)>(cvoff[0], slot + 8 * (wn0 + frow));
-        lds_read64<8 * (BM + BN + BM + 16)>(cvoff[1], slot + 8 * (wn0 + frow));
-        row_lds = slot + 8 * (BM + BN + wm0 + (lane >> 4));
+        lds_read64<8 * BM>(cvoff[0], slot + 8 * (wn0 + frow));
+        lds_read64<8 * (BM + 16)>(cvoff[1], slot + 8 * (wn0 + frow));
+        row_lds = slot + 8 * (wm0 + (lane >> 4));
         row_read(std::integral_constant<int, 0>());
     };
     auto finish_cols = [&]() {
@@ -387,7 +433,7 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
     };
 
 #ifdef CTC_SX_STAMPS  // diagnostic build: shader-clock ticks per K-tile kind, split at the wait + barrier
-    unsigned long long st_body[3] = {0, 0, 0}, st_sync[3] = {0, 0, 0}, st_n[3] = {0, 0, 0}, st_t0 = 0, st_t1 = 0, st_t2 = 0;
+    unsigned long long st_body[STORE_TILES + 1] = {}, st_sync[STORE_TILES + 1] = {}, st_n[STORE_TILES + 1] = {}, st_t0 = 0, st_t1 = 0, st_t2 = 0;
 #define CTC_SX_STAMP(var)                                                        \
     do {                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                       \
@@ -399,6 +445,7 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
 #endif
     auto tile_step = [&](auto set_t, auto var_t, auto full_t, int X, int kt) {
         constexpr int SET = decltype(set_t)::value, VAR = decltype(var_t)::value;
+        constexpr bool FULL_T = decltype(full_t)::value;
         CTC_SX_STAMP(st_t0);
         const unsigned cur = smem_lds + stage_cur * kStageBytes;
         const int stage_next = stage_cur == kStages - 1 ? 0 : stage_cur + 1;
@@ -412,8 +459,10 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
         const int k0_load = kt2 * BK;
         const int64_t kofs_a = (int64_t)k0_load * 8 * p.ka_stride, kofs_b = (int64_t)k0_load * 8 * p.kb_stride;
         const bool loader_switch = (kt == nk - 2) && has_next;
-        const unsigned slot_prev = ring_lds + ((X + 3) & 3) * (kRingEntries * 8);
-        const unsigned slot_next = ring_lds + ((X + 1) & 3) * (kRingEntries * 8);
+        const unsigned slot_prev = ring_lds + 8 * G_::c_entry(X + 3);   // C offsets of item X - 1
+        const unsigned slot_next = ring_lds + 8 * G_::ab_entry(X + 1);  // A / B offsets of item X + 1
+        const bool ring_tile = TWO ? (kt == nk - 1) : (VAR == 0);        // this tile requests item X + 2's offsets
+        constexpr int RING_IDX = TWO ? NIDX - 4 : NIDX - NMFMA - 2;      // K-tile 16: behind the barrier
         static_for<0, KSTEPS>([&](auto kk_t) {
             constexpr int kk = decltype(kk_t)::value;
             constexpr int s = kk & 1;
@@ -432,7 +481,7 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
 #ifdef CTC_SX_NOWAITV  // diagnostic builds (wrong results): tools/build_variant.sh
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA + (FULL_T && VAR < STORE_TILES ? STORES_AHEAD : 0)) : "memory");
 #endif
 #ifndef CTC_SX_NOBARRIER
                 __builtin_amdgcn_s_barrier();
@@ -474,7 +523,7 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
                 // item bookkeeping
                 if (VAR == 0 && idx == 0) load_cols(slot_prev);
                 if (VAR == 0 && idx == 1) finish_cols();
-                if (VAR == 0 && idx == NIDX - NMFMA - 2 && has_next2) ring_fetch(X + 2);
+                if (idx == RING_IDX && ring_tile && has_next2) ring_fetch(X + 2);
                 // stores of the previous item, one every SPACING MFMAs
                 if (VAR < STORE_TILES) {
                     static_for<0, SPT>([&](auto u_t) {
@@ -506,17 +555,14 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
         // stores carry no per-lane bounds and no branches
         const bool prev_full = m_lim_prev == BM && n_lim_prev == BN;
         if (prev_full) {
-            tile_step(set_t, std::integral_constant<int, 0>(), std::true_type(), X, 0);
-            m_lim_q[2] = m_lim_new;
-            n_lim_q[2] = n_lim_new;
-            tile_step(set_t, std::integral_constant<int, 1>(), std::true_type(), X, 1);
+            static_for<0, STORE_TILES>([&](auto v_t) { tile_step(set_t, v_t, std::true_type(), X, decltype(v_t)::value); });
         } else {
-            tile_step(set_t, std::integral_constant<int, 0>(), std::false_type(), X, 0);
-            m_lim_q[2] = m_lim_new;
-            n_lim_q[2] = n_lim_new;
-            tile_step(set_t, std::integral_constant<int, 1>(), std::false_type(), X, 1);
+            static_for<0, STORE_TILES>([&](auto v_t) { tile_step(set_t, v_t, std::false_type(), X, decltype(v_t)::value); });
         }
-        for (int kt = STORE_TILES; kt < nk; ++kt) tile_step(set_t, std::integral_constant<int, 2>(), std::true_type(), X, kt);
+        for (int kt = STORE_TILES; kt < nk; ++kt)
+            tile_step(set_t, std::integral_constant<int, STORE_TILES>(), std::true_type(), X, kt);
+        m_lim_q[2] = m_lim_new;  // of item X + 2, whose offsets one of these tiles requested
+        n_lim_q[2] = n_lim_new;
         // this item is the "previous item" of the next one
         m_lim_prev = m_lim_q[0]; n_lim_prev = n_lim_q[0];
         m_lim_q[0] = m_lim_q[1]; n_lim_q[0] = n_lim_q[1];
@@ -529,19 +575,19 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
     }
 
     // the last item's stores: nothing left to hide them behind
-    auto flush = [&](auto set_t, const int64_t *slot) {
+    auto flush = [&](auto set_t, const int64_t *slot) {  // slot: the item's [C rows | C columns] run
         constexpr int SET = decltype(set_t)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm0 + 16 * i + Tr::acc_row(lane, r);
-                const int64_t ro = slot[BM + BN + row];
+                const int64_t ro = slot[row];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int col = wn0 + 16 * j + frow;
                     if (row < m_lim_prev && col < n_lim_prev)
-                        __builtin_nontemporal_store(acc[SET][i][j][r], C + ro + slot[BM + BN + BM + col]);
+                        __builtin_nontemporal_store(acc[SET][i][j][r], C + ro + slot[BM + col]);
                 }
             }
     };
@@ -549,21 +595,47 @@ __global__ void __launch_bounds__(256, 1) gemm_stream_f64_kernel(const GemmParam
     if (t == 0 && (bid == 0 || bid == 77))
         printf("[stamps] block %d items %d | per K-tile ticks body/sync: first %llu/%llu second %llu/%llu later %llu/%llu (n %llu %llu %llu)\n", bid,
                n_items, st_body[0] / (st_n[0] ? st_n[0] : 1), st_sync[0] / (st_n[0] ? st_n[0] : 1), st_body[1] / (st_n[1] ? st_n[1] : 1),
-               st_sync[1] / (st_n[1] ? st_n[1] : 1), st_body[2] / (st_n[2] ? st_n[2] : 1), st_sync[2] / (st_n[2] ? st_n[2] : 1), st_n[0],
-               st_n[1], st_n[2]);
+               st_sync[1] / (st_n[1] ? st_n[1] : 1), st_body[STORE_TILES] / (st_n[STORE_TILES] ? st_n[STORE_TILES] : 1),
+               st_sync[STORE_TILES] / (st_n[STORE_TILES] ? st_n[STORE_TILES] : 1), st_n[0], st_n[1], st_n[STORE_TILES]);
+#endif
+#ifdef CTC_SX_CLOCK
+    if (t == 0 && (bid == 0 || bid == 77)) {
+        const unsigned long long dc = __builtin_readcyclecounter() - ck_core0, dr = __builtin_amdgcn_s_memrealtime() - ck_real0;
+        printf("[clock] block %d: %llu core ticks in %llu x 10 ns -> %.3f GHz\n", bid, dc, dr, (double)dc / (10.0 * (double)dr));
+    }
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMAs past the end of the stream have landed before the LDS goes away
-    const int64_t *slot_last = &s_ring[(n_items - 1) & 3][0];
+    const int64_t *slot_last = &s_ring[G_::c_entry(n_items - 1)];
     if ((n_items - 1) & 1) flush(std::integral_constant<int, 1>(), slot_last);
     else flush(std::integral_constant<int, 0>(), slot_last);
 }
 
-template <int LA, int LB> hipError_t launch_one(const GemmParams &p, hipStream_t stream)
+// workgroups of the current device that are resident at once, per kernel instantiation
+template <int LA, int LB, int BK> hipError_t resident_workgroups(int *out)
 {
-    int dev = 0, cus = 0;
+    static std::atomic<int> cache[64];  // 0: not queried yet
+    int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (cache[dev].load() == 0) {
+        int cus = 0, per_cu = 0;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_stream_f64_kernel<LA, LB, BK>, 256, 0);
+        if (e != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 2) per_cu = 2;
+        cache[dev].store(cus * per_cu);
+    }
+    *out = cache[dev].load();
+    return hipSuccess;
+}
+
+template <int LA, int LB, int BK> hipError_t launch_one(const GemmParams &p, hipStream_t stream)
+{
+    int slots = 0;
+    hipError_t e = resident_workgroups<LA, LB, BK>(&slots);
     if (e != hipSuccess) return e;
     GemmParams q = p;
     q.nbm = (int)((p.M + kBM - 1) / kBM);
@@ -571,17 +643,24 @@ template <int LA, int LB> hipError_t launch_one(const GemmParams &p, hipStream_t
     if (q.group < 1) q.group = 1;
     const int64_t tiles = (int64_t)q.nbm * q.nbn;
     if (tiles > 0x7FFFFFFF) return hipErrorInvalidValue;
-    const int grid = (int)(tiles < cus ? tiles : cus);
-    hipLaunchKernelGGL((gemm_stream_f64_kernel<LA, LB>), dim3((unsigned)grid), dim3(256), 0, stream, q);
+    const int grid = (int)(tiles < slots ? tiles : slots);
+    hipLaunchKernelGGL((gemm_stream_f64_kernel<LA, LB, BK>), dim3((unsigned)grid), dim3(256), 0, stream, q);
     return hipGetLastError();
 }
 
 }  // namespace
 
+// diagnostic switch: CTC_TC_STREAM_BK=32 keeps the one-workgroup-per-CU geometry for every layout
+static int stream_bk()
+{
+    static const int bk = getenv("CTC_TC_STREAM_BK") ? atoi(getenv("CTC_TC_STREAM_BK")) : 16;
+    return bk == 32 ? 32 : 16;
+}
+
 bool stream_gemm_f64_dma_supported(int layout_a, int layout_b, const GemmParams &p)
 {
     return (layout_a == 0 || layout_a == 1) && (layout_b == 0 || layout_b == 1) && p.batch == 1 && p.beta == 0.0 &&
-           p.alpha == 1.0 && p.K > kBK && p.K % kBK == 0 && p.M >= 2 && p.N >= 2 && p.M % 2 == 0 && p.N % 2 == 0 &&
+           p.alpha == 1.0 && p.K > 32 && p.K % 32 == 0 && p.M >= 2 && p.N >= 2 && p.M % 2 == 0 && p.N % 2 == 0 &&
            p.ka_stride > 0 && p.kb_stride > 0;
 }
 
@@ -590,11 +669,11 @@ hipError_t launch_gemm_stream_f64_dma(int layout_a, int layout_b, const GemmPara
     if (!stream_gemm_f64_dma_supported(layout_a, layout_b, p)) return hipErrorInvalidValue;
     switch (layout_a * 2 + layout_b) {
 #ifndef CTC_SX_ONE  // diagnostic builds of the outer/outer instantiation only (tools/build_variant.sh)
-    case 0: return launch_one<0, 0>(p, stream);
-    case 1: return launch_one<0, 1>(p, stream);
-    case 2: return launch_one<1, 0>(p, stream);
+    case 0: return launch_one<0, 0, 32>(p, stream);
+    case 1: return launch_one<0, 1, 32>(p, stream);
+    case 2: return launch_one<1, 0, 32>(p, stream);
 #endif
-    case 3: return launch_one<1, 1>(p, stream);
+    case 3: return stream_bk() == 32 ? launch_one<1, 1, 32>(p, stream) : launch_one<1, 1, 16>(p, stream);
     default: return hipErrorInvalidValue;
     }
 }
