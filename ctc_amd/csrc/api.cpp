@@ -263,6 +263,9 @@ size_t worst_splitk_bytes(const ctc::Plan &p)
     ctc::GemmParams g;
     g.M = p.M; g.N = p.N; g.K = p.K;
     g.batch = (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch);
+    g.k8_affine = (p.k8_affine && p.max_row_a < (int64_t(1) << 28) && p.max_col_b < (int64_t(1) << 28)) ? 1 : 0;
+    g.ka_in = p.ka_in;
+    g.kb_in = p.kb_in;
     size_t worst = 0;
     for (int va = 0; va < 2; ++va)
         for (int vb = 0; vb < 2; ++vb) {
@@ -330,6 +333,11 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     g.c_vec = (p.vec_c > 1 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) ? p.vec_c : 1;
     // a result larger than the 256 MiB Infinity Cache cannot stay resident for a consumer anyway
     g.c_stream = (double)p.M * (double)p.N * (double)p.batch * (double)ctc::dtype_size(p.dtype) > 256.0 * 1048576.0;
+
+    // one table entry per K-tile of 8 and 32-bit lane offsets: what the LDS-DMA kernel needs
+    g.k8_affine = (p.k8_affine && p.max_row_a < (int64_t(1) << 28) && p.max_col_b < (int64_t(1) << 28)) ? 1 : 0;
+    g.ka_in = p.ka_in;
+    g.kb_in = p.kb_in;
 
     // vector loads need 16-byte aligned bases; otherwise fall back to element loads
     int la = p.layout_a, lb = p.layout_b;

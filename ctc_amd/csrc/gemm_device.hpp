@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 
 #include <cstdint>
+#include <type_traits>
 
 namespace ctc {
 namespace gemm_detail {
@@ -99,6 +100,110 @@ template <typename V> __device__ __forceinline__ V zero_of()
 {
     V v = {};
     return v;
+}
+
+// sentinel in a tile's staged C offsets: the row / column lies outside C
+constexpr int64_t kNoOffset = INT64_MIN;
+
+// Epilogue of a BM x BN tile held as TM x TN 16 x 16 accumulators per wave (wave origin wm0, wn0; s_coff:
+// the tile's BM row offsets, then its BN column offsets, kNoOffset outside C).  partial: the workgroup
+// multiplied K chunk `chunk` of split tile `sid`; its raw sums go to the workspace.  Every lane of the
+// wave must call.
+template <typename T, int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void store_tile(const GemmParams &p, typename Traits<T>::acc_t (&acc)[TM][TN],
+                                           const int64_t *s_coff, T *C, int wm0, int wn0, int lane, bool partial,
+                                           int sid, int chunk)
+{
+    typedef Traits<T> Tr;
+    const int frow = lane & 15;
+    // Epilogue: lanes 0..15 of each quarter-wave hold 16 consecutive N positions of
+    // one row, so every store instruction writes four contiguous runs of C.  The
+    // beta test is hoisted so the common beta == 0 path is a straight run of stores.
+    if (partial) {
+        // raw accumulators of this K chunk: tile-shaped slab [BM][BN] in the workspace
+        T *slab = static_cast<T *>(p.ws) + ((int64_t)(sid - p.dp_tiles) * p.split + chunk) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm0 + 16 * i + Tr::acc_row(lane, r);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) slab[row * BN + wn0 + 16 * j + frow] = acc[i][j][r];
+            }
+        return;
+    }
+    const T alpha = (T)p.alpha, beta = (T)p.beta;
+    int64_t coff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) coff[j] = s_coff[BM + wn0 + 16 * j + frow];
+    int64_t roff[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) roff[i][r] = s_coff[wm0 + 16 * i + Tr::acc_row(lane, r)];
+    auto store_rows = [&](auto with_beta_t) {
+        constexpr bool WITH_BETA = decltype(with_beta_t)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#ifdef CTC_EXP_NOSTORE
+                    if (roff[i][r] != kNoOffset && coff[j] != kNoOffset && acc[i][j][r] == (T)1.2345e30) {
+#else
+                    if (roff[i][r] != kNoOffset && coff[j] != kNoOffset) {
+#endif
+                        T *dst = C + roff[i][r] + coff[j];
+                        T v = alpha * acc[i][j][r];
+                        if (WITH_BETA) v += beta * *dst;
+                        *dst = v;
+                    }
+                }
+            }
+        }
+    };
+    // Same with 16-byte stores (see Traits::cvec): half (f64) or a quarter (f32) of the store
+    // instructions, which is what bounds the epilogue of contractions with a short K.
+    // STREAM: C does not fit the Infinity Cache, so its lines are stored with the non-temporal hint and
+    // leave the caches to the operand panels (config-4 contraction with |C| = 32.8 GB: 41.4 -> 47.7 TFLOP/s).
+    auto store_rows_vec = [&](auto with_beta_t, auto stream_t) {
+        constexpr bool WITH_BETA = decltype(with_beta_t)::value;
+        constexpr bool STREAM = decltype(stream_t)::value;
+        typedef typename Tr::vec_t vec_t;
+        int64_t cvoff[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) cvoff[j] = s_coff[BM + wn0 + 16 * j + (frow & ~(Tr::CV - 1))];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int s = 0; s < Tr::NCV; ++s) {
+                const int64_t rvoff = s_coff[wm0 + 16 * i + Tr::cvec_row(lane, s)];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    vec_t v = Tr::cvec(acc[i][j], lane, s) * alpha;
+#ifdef CTC_EXP_NOSTORE
+                    if (rvoff != kNoOffset && cvoff[j] != kNoOffset && v[0] == (T)1.2345e30) {
+#else
+                    if (rvoff != kNoOffset && cvoff[j] != kNoOffset) {
+#endif
+                        vec_t *dst = reinterpret_cast<vec_t *>(C + rvoff + cvoff[j]);
+                        if (WITH_BETA) v += *dst * beta;
+                        if (STREAM) __builtin_nontemporal_store(v, dst);
+                        else *dst = v;
+                    }
+                }
+            }
+        }
+    };
+    if (p.c_vec > 1) {
+        if (beta != (T)0) store_rows_vec(std::true_type(), std::false_type());
+        else if (p.c_stream) store_rows_vec(std::false_type(), std::true_type());
+        else store_rows_vec(std::false_type(), std::false_type());
+    } else {
+        if (beta == (T)0) store_rows(std::false_type());
+        else store_rows(std::true_type());
+    }
 }
 
 // Stages a BR x BK operand tile: global -> registers -> LDS.

@@ -1,0 +1,414 @@
+// fp64 MFMA GEMM, one 128 x 128 tile of C per workgroup as in gemm_kernels.hip, with the operands staged
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4) instead of through registers:
+//   - the waves hold no staging registers and execute no LDS writes; per K-tile a wave issues four DMA
+//     instructions whose addresses are one 32-bit lane offset (fixed for the whole tile of C) on top of a
+//     wave-uniform 64-bit base, so staging costs the vector ALU nothing.  On MI355X the fp64 MFMA shares the
+//     vector ALU, and the register-staged kernel spends about three vector instructions per MFMA there;
+//   - K-tiles of 8 in a ring of four 16 KB stages (64 KB: two workgroups per CU): during K-tile t the DMA of
+//     K-tile t + 3 is issued, the one of t + 1 is awaited (counted s_waitcnt: the memory counter retires in
+//     order) just before the single barrier of the tile;
+//   - a DMA instruction writes 1 KB of consecutive LDS (16 bytes per lane), so bank conflicts are removed by
+//     choosing WHICH 16-byte chunk a lane fetches instead of by padding:
+//       K-major operand (unit stride along K):   image [row][8 k] (64-byte rows), chunk c of row r stored at
+//           chunk position c ^ ((r >> 2) & 3);
+//       outer-major operand (unit stride along the rows): image [k][128 rows], chunk c (rows 2c, 2c + 1) of
+//           line k stored at position c ^ ((k & 1) << 3);
+//   - fragment reads are inline-assembly ds_read_b64 with the stage, the row block and the k-step in the
+//     instruction's offset field (the K-tile loop is unrolled over the four stages), two address registers
+//     per operand.
+// Needs: both operands in a 16-byte-vector layout, K a multiple of 8, k offsets that are affine inside every
+// aligned group of 8 (GemmParams::k8_affine; e.g. every contracted mode's extent a multiple of 8, or one
+// contracted mode), row / column offsets below 2^28 elements.  Everything else takes gemm_kernels.hip.
+// Tile order, split of the last round along K, epilogue: as there.
+#include "gemm_device.hpp"
+#include "kernels.hpp"
+#include "lds_dma.hpp"
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace ctc {
+
+namespace {
+
+using namespace gemm_detail;
+using namespace lds_dma;
+
+constexpr int kBM = 128, kBN = 128, kBK = 8, kStages = 4;
+constexpr int kOpBytes = 128 * kBK * 8;    // one operand's tile image
+constexpr int kStageBytes = 2 * kOpBytes;  // A image, then B image
+
+// What a lane fetches for its two DMA instructions per K-tile of one operand, and where a lane's MFMA
+// fragments sit in the operand's image.
+template <int LAY> struct Operand {
+    static constexpr bool KMAJ = (LAY != kLayOuterVec);
+    unsigned off[2];   // byte offset of the lane's 16 bytes from the wave-uniform base, instructions 0 and 1
+    unsigned frag[2];  // LDS byte addresses (stage 0, row block 0, k-step 0): KMAJ k-step 0 / 1, else even / odd row block
+
+    // tab: the operand's row (column) offsets, r0: first row of the tile, R: the operand's extent;
+    // instruction j of wave `wave` fills bytes [(2 wave + j) KB, + 1 KB) of the image
+    __device__ __forceinline__ void init_dma(const int64_t *__restrict__ tab, int64_t r0, int64_t R, int lane, int wave)
+    {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (KMAJ) {
+                // 16 rows per instruction, 4 chunks per row
+                const int row = 16 * (2 * wave + j) + (lane >> 2);
+                const int c = (lane & 3) ^ ((lane >> 4) & 3);
+                int64_t g = r0 + row;
+                if (g > R - 1) g = R - 1;  // rows past the extent repeat its last row: products never stored
+                off[j] = (unsigned)(tab[g] * 8 + c * 16);
+            } else {
+                // one line per instruction (k = 2 wave + j, parity j), 64 chunks of two rows
+                const int c = lane ^ (j << 3);
+                int64_t g = r0 + 2 * c;
+                if (g > R - 2) g = R - 2;  // R is even: a pair never straddles the end
+                off[j] = (unsigned)(tab[g] * 8);
+            }
+        }
+    }
+    // w0: first row of the wave's part of the tile; image: LDS address of the operand's image in stage 0
+    __device__ __forceinline__ void init_frag(unsigned image, int frow, int fk, int w0)
+    {
+        if (KMAJ) {
+            const int r2 = (frow >> 2) & 3;
+            const int phys0 = ((fk >> 1) ^ (r2 & 1)) | ((r2 >> 1) << 1);
+            const unsigned base = image + (w0 + frow) * 64 + phys0 * 16 + (fk & 1) * 8;
+            frag[0] = base;
+            frag[1] = base ^ 32;
+        } else {
+            const int p = fk & 1;
+            const unsigned base = image + fk * 1024 + ((w0 + frow) >> 1) * 16 + (frow & 1) * 8;
+            frag[0] = base + 128 * p;
+            frag[1] = base - 128 * p;
+        }
+    }
+    template <int b, int kk> __device__ __forceinline__ unsigned frag_reg() const { return frag[KMAJ ? kk : (b & 1)]; }
+    template <int b, int kk> static constexpr int frag_imm() { return KMAJ ? b * 1024 : 128 * b + kk * 4096; }
+    // wave-uniform byte offset of instruction j of the K-tile whose first k offset (elements) is kofs
+    __device__ __forceinline__ static int64_t uniform(int64_t kofs, int64_t kin, int wave, int j)
+    {
+        return KMAJ ? kofs * 8 : (kofs + (int64_t)(2 * wave + j) * kin) * 8;
+    }
+};
+
+template <int LA, int LB>
+__global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p)
+{
+    constexpr int BM = kBM, BN = kBN, BK = kBK, WN = 2;
+    constexpr int TM = 4, TN = 4, NMFMA = TM * TN;
+    static_assert(BK == 8, "two k-steps per K-tile");
+    typedef Traits<double> Tr;
+    typedef Tr::acc_t acc_t;
+    constexpr int NDMA = 4;  // per wave per K-tile
+
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes];
+    __shared__ int64_t s_coff[BM + BN];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm0 = (wave / WN) * (TM * 16);
+    const int wn0 = (wave % WN) * (TN * 16);
+    const int frow = lane & 15;
+    const int fk = lane >> 4;
+
+    // block -> tile, as in gemm_kernel: XCD-contiguous runs of tile ids, groups of tile rows, the tiles of
+    // the last round cut along K
+    int sid, chunk = 0;
+    bool partial = false;
+    {
+        const int bid = blockIdx.x;
+        if (bid < p.dp_tiles) {
+            const int nblk = p.dp_tiles;
+            const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+            sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        } else {
+            const int item = bid - p.dp_tiles;
+            sid = p.dp_tiles + item / p.split;
+            chunk = item % p.split;
+            partial = true;
+        }
+    }
+    const int width = p.group * p.nbn;
+    const int first_m = (sid / width) * p.group;
+    const int gsz = min(p.nbm - first_m, p.group);
+    const int tm = first_m + (sid % width) % gsz;
+    const int tn = (sid % width) / gsz;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int64_t n0 = (int64_t)tn * BN;
+    const int bz = blockIdx.y;
+
+    const char *A = reinterpret_cast<const char *>(static_cast<const double *>(p.A) + p.bat_a[bz]);
+    const char *B = reinterpret_cast<const char *>(static_cast<const double *>(p.B) + p.bat_b[bz]);
+    double *C = static_cast<double *>(p.C) + p.bat_c[bz];
+
+    const int nk_total = (int)(p.K / BK);
+    const int kt_first = partial ? (int)((int64_t)chunk * nk_total / p.split) : 0;
+    const int kt_last = partial ? (int)((int64_t)(chunk + 1) * nk_total / p.split) : nk_total;
+    const int nk = kt_last - kt_first;
+
+    // everything that goes through ordinary loads and LDS stores comes first: once a DMA is in flight the
+    // compiler drains it in front of every LDS access it can see
+    if (!partial) {
+        for (int idx = t; idx < BM + BN; idx += 256) {
+            const bool is_row = idx < BM;
+            const int64_t g = is_row ? m0 + idx : n0 + (idx - BM);
+            const bool ok = g < (is_row ? p.M : p.N);
+            const int64_t off = (is_row ? p.row_c : p.col_c)[ok ? g : 0];
+            s_coff[idx] = ok ? off : kNoOffset;
+        }
+    }
+    Operand<LA> oa;
+    Operand<LB> ob;
+    oa.init_dma(p.row_a, m0, p.M, lane, wave);
+    ob.init_dma(p.col_b, n0, p.N, lane, wave);
+    const unsigned smem_lds = lds_addr(smem);
+    oa.init_frag(smem_lds, frow, fk, wm0);
+    ob.init_frag(smem_lds + kOpBytes, frow, fk, wn0);
+
+    acc_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = zero_of<acc_t>();
+
+    // K-tiles are requested in order, three ahead; past the chunk's end the requests wrap to its first
+    // tiles (finite data nobody multiplies) so that every wave issues the same number of DMAs per tile
+    // Its k offsets come by SCALAR loads issued from assembly (the compiler would take vector loads here,
+    // whose first use drains every DMA in flight); asynchronous: k_wait() before the first use.
+    int tl = 0;  // tile the next request is for, relative to kt_first
+    int64_t ka_next, kb_next;
+    auto k_fetch = [&]() {
+        const int64_t *pa = p.k_a + (int64_t)(kt_first + tl) * BK, *pb = p.k_b + (int64_t)(kt_first + tl) * BK;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(ka_next) : "s"(pa));
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(kb_next) : "s"(pb));
+    };
+    auto k_wait = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ka_next), "+s"(kb_next)); };
+    auto advance = [&]() {
+        tl = (tl + 1 == nk) ? 0 : tl + 1;
+        k_fetch();
+    };
+    k_fetch();
+    k_wait();
+    // instruction u (0, 1: A; 2, 3: B) of the requested tile into stage `stage`
+    auto issue = [&](int u, unsigned char *stage, int64_t ka, int64_t kb) {
+        const int j = u & 1;
+        if (u < 2) dma16(A + Operand<LA>::uniform(ka, p.ka_in, wave, j) + oa.off[j], stage + (2 * wave + j) * 1024);
+        else dma16(B + Operand<LB>::uniform(kb, p.kb_in, wave, j) + ob.off[j], stage + kOpBytes + (2 * wave + j) * 1024);
+    };
+    __syncthreads();  // s_coff is written; no DMA is in flight yet
+#pragma unroll
+    for (int s = 0; s < kStages - 1; ++s) {
+#pragma unroll
+        for (int u = 0; u < NDMA; ++u) issue(u, smem + s * kStageBytes, ka_next, kb_next);
+        advance();
+        k_wait();
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");  // K-tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+
+    double fa[2][TM], fb[2][TN];
+    // fragments of k-step KK of stage S into slot SLOT; asynchronous (frags_wait)
+    auto read_frags = [&](auto slot_t, auto kk_t, auto stage_t) {
+        constexpr int SLOT = decltype(slot_t)::value, KK = decltype(kk_t)::value, S = decltype(stage_t)::value;
+        static_for<0, TM>([&](auto b_t) {
+            constexpr int b = decltype(b_t)::value;
+            lds_read64<S * kStageBytes + Operand<LA>::template frag_imm<b, KK>()>(fa[SLOT][b], oa.template frag_reg<b, KK>());
+        });
+        static_for<0, TN>([&](auto b_t) {
+            constexpr int b = decltype(b_t)::value;
+            lds_read64<S * kStageBytes + Operand<LB>::template frag_imm<b, KK>()>(fb[SLOT][b], ob.template frag_reg<b, KK>());
+        });
+    };
+    auto frags_wait = [&](auto slot_t) {
+        constexpr int SLOT = decltype(slot_t)::value;
+        static_assert(TM == 4 && TN == 4, "operand list of lds_wait");
+        lds_wait(fa[SLOT][0], fa[SLOT][1], fa[SLOT][2], fa[SLOT][3], fb[SLOT][0], fb[SLOT][1], fb[SLOT][2], fb[SLOT][3]);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    read_frags(I0(), I0(), I0());
+
+    // One K-tile out of stage S.  Every instruction that is not an MFMA is dealt out behind one, in an order
+    // pinned with sched_barrier:
+    //   k-step 0: fragment reads of k-step 1; the four DMAs of K-tile +3 into stage S + 3;
+    //   wait (K-tile +1 has landed: the eight DMAs issued since may still be in flight), barrier (every
+    //   wave's part of it is there, and every wave is done reading stage S, which the next tile's DMAs overwrite);
+    //   k-step 1: first fragment reads of K-tile +1; the k offsets of the tile requested next.
+    auto tile_step = [&](auto stage_t) {
+        constexpr int S = decltype(stage_t)::value, SN = (S + 1) % kStages, SL = (S + kStages - 1) % kStages;
+        unsigned char *ld = smem + SL * kStageBytes;
+        frags_wait(I0());
+        k_wait();  // requested a k-step ago, and the fragment wait has covered it
+        const int64_t ka = ka_next, kb = kb_next;
+        static_for<0, NMFMA>([&](auto q_t) {
+            constexpr int q = decltype(q_t)::value;
+            acc[q / TN][q % TN] = Tr::mfma(fa[0][q / TN], fb[0][q % TN], acc[q / TN][q % TN]);
+            if (q == 0) read_frags(I1(), I1(), stage_t);
+            if (q >= 2 && q < 2 + 3 * NDMA && (q - 2) % 3 == 0) issue((q - 2) / 3, ld, ka, kb);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // a bare s_barrier: __syncthreads() carries a fence, which with LDS-DMA in flight becomes a full
+        // drain of the memory counter.  What the fence would order is ordered by hand: this wave's DMAs of
+        // K-tile +1 have landed (vmcnt), its reads of stage S have returned (lgkmcnt).
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        frags_wait(I1());
+        static_for<0, NMFMA>([&](auto q_t) {
+            constexpr int q = decltype(q_t)::value;
+            acc[q / TN][q % TN] = Tr::mfma(fa[1][q / TN], fb[1][q % TN], acc[q / TN][q % TN]);
+            if (q == 0) read_frags(I0(), I0(), std::integral_constant<int, SN>());
+            if (q == 1) advance();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    {
+        int kt = 0;
+        for (; kt + kStages <= nk; kt += kStages) {
+            tile_step(std::integral_constant<int, 0>());
+            tile_step(std::integral_constant<int, 1>());
+            tile_step(std::integral_constant<int, 2>());
+            tile_step(std::integral_constant<int, 3>());
+        }
+        if (kt < nk) tile_step(std::integral_constant<int, 0>());
+        if (kt + 1 < nk) tile_step(std::integral_constant<int, 1>());
+        if (kt + 2 < nk) tile_step(std::integral_constant<int, 2>());
+    }
+    // the requests past the end have landed before the LDS goes away, and the last fragment reads (of a
+    // tile nobody multiplies) have returned
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    frags_wait(I0());
+
+    store_tile<double, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, sid, chunk);
+}
+
+template <int LA, int LB> int resident_slots()
+{
+    static std::atomic<int> cache[64];  // 0: not queried yet; host threads of several devices may race here
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cache[dev].load() == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_f64_kernel<LA, LB>, 256, 0) != hipSuccess) return 0;
+        cache[dev].store(cus * per_cu > 0 ? cus * per_cu : -1);
+    }
+    const int slots = cache[dev].load();
+    return slots > 0 ? slots : 0;
+}
+
+// chunk overhead of the split along K, in K-tiles (of 8 here): prologue, raw sums to the workspace, the
+// chunk's share of the fix-up pass; the same 128 contracted elements as in gemm_kernels.hip
+constexpr int kMinChunkTiles = 16;
+
+int best_split(int64_t tail, int slots, int nk)
+{
+    int fmax = nk / kMinChunkTiles;
+    if (fmax > 1024) fmax = 1024;
+    int best_f = 1;
+    double best = (double)nk;
+    for (int f = 2; f <= fmax; ++f) {
+        const double rounds = (double)((tail * f + slots - 1) / slots);
+        const double cost = rounds * ((double)nk / f + kMinChunkTiles);
+        if (cost < best * 0.98) {
+            best = cost;
+            best_f = f;
+        }
+    }
+    return best_f;
+}
+
+template <int LA, int LB> hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
+{
+    GemmSchedule s;
+    s.nbm = (int)((p.M + kBM - 1) / kBM);
+    s.nbn = (int)((p.N + kBN - 1) / kBN);
+    const int64_t tiles = (int64_t)s.nbm * s.nbn;
+    if (tiles > 0x7FFFFFFF) return hipErrorInvalidValue;
+    s.dp_tiles = (int)tiles;
+    s.split = 1;
+    s.tail_tiles = 0;
+    s.ws_bytes = 0;
+    static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
+    const int slots = resident_slots<LA, LB>();
+    const int nk = (int)(p.K / kBK);
+    if (!no_split && slots > 0 && p.batch == 1) {
+        const int tail = (int)(tiles % slots);
+        if (tail > 0) {
+            const int f = best_split(tail, slots, nk);
+            if (f >= 2) {
+                s.tail_tiles = tail;
+                s.dp_tiles = (int)tiles - tail;
+                s.split = f;
+                s.ws_bytes = (size_t)tail * f * kBM * kBN * sizeof(double);
+            }
+        }
+    }
+    *out = s;
+    return hipSuccess;
+}
+
+template <int LA, int LB>
+hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
+{
+    GemmParams q = p;
+    q.nbm = sch.nbm;
+    q.nbn = sch.nbn;
+    q.dp_tiles = sch.dp_tiles;
+    q.split = sch.split;
+    q.ws = ws;
+    if (q.group < 1) q.group = 1;
+    if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
+    dim3 grid((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1);
+    hipLaunchKernelGGL((gemm_dma_f64_kernel<LA, LB>), grid, dim3(256), 0, stream, q);
+    if (sch.tail_tiles > 0) {
+        hipError_t e = launch_splitk_fixup_f64(q, sch.tail_tiles, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool dma_gemm_f64_supported(int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
+{
+    static const bool off = getenv("CTC_TC_NO_DMA_GEMM") != nullptr;
+    if (off || bm != kBM || bn != kBN) return false;
+    if ((layout_a != 0 && layout_a != 1) || (layout_b != 0 && layout_b != 1)) return false;
+    if (p.k8_affine == 0 || p.K < kBK || p.K % kBK != 0 || p.batch < 1 || p.batch > 65535) return false;
+    if (p.M < 2 || p.N < 2) return false;
+    if (layout_a == 1 && p.M % 2 != 0) return false;
+    if (layout_b == 1 && p.N % 2 != 0) return false;
+    if (layout_a == 0 && p.ka_in != 1) return false;
+    if (layout_b == 0 && p.kb_in != 1) return false;
+    return true;
+}
+
+hipError_t schedule_gemm_dma_f64(int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out)
+{
+    switch (layout_a * 2 + layout_b) {
+    case 0: return schedule_one<0, 0>(p, out);
+    case 1: return schedule_one<0, 1>(p, out);
+    case 2: return schedule_one<1, 0>(p, out);
+    case 3: return schedule_one<1, 1>(p, out);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_gemm_dma_f64(int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
+                               void *workspace, hipStream_t stream)
+{
+    switch (layout_a * 2 + layout_b) {
+    case 0: return launch_one<0, 0>(p, schedule, workspace, stream);
+    case 1: return launch_one<0, 1>(p, schedule, workspace, stream);
+    case 2: return launch_one<1, 0>(p, schedule, workspace, stream);
+    case 3: return launch_one<1, 1>(p, schedule, workspace, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ctc

@@ -79,7 +79,6 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     // element offsets of the tile's C rows and columns (kNoOffset: outside C), fetched in the
     // prologue so that the epilogue issues its stores without waiting on any global load
     __shared__ int64_t s_coff[BM + BN];
-    constexpr int64_t kNoOffset = INT64_MIN;
     constexpr int STAGE_ELEMS = SA::LDS_ELEMS + SB::LDS_ELEMS;
 
     const int t = threadIdx.x;
@@ -304,94 +303,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     CTC_STAMP(st_loop1);
 #endif
 
-    // Epilogue: lanes 0..15 of each quarter-wave hold 16 consecutive N positions of
-    // one row, so every store instruction writes four contiguous runs of C.  The
-    // beta test is hoisted so the common beta == 0 path is a straight run of stores.
-    if (partial) {
-        // raw accumulators of this K chunk: tile-shaped slab [BM][BN] in the workspace
-        T *slab = static_cast<T *>(p.ws) + ((int64_t)(sid - p.dp_tiles) * p.split + chunk) * (BM * BN);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm0 + 16 * i + Tr::acc_row(lane, r);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) slab[row * BN + wn0 + 16 * j + frow] = acc[i][j][r];
-            }
-        return;
-    }
-    const T alpha = (T)p.alpha, beta = (T)p.beta;
-    int64_t coff[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) coff[j] = s_coff[BM + wn0 + 16 * j + frow];
-    int64_t roff[TM][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) roff[i][r] = s_coff[wm0 + 16 * i + Tr::acc_row(lane, r)];
-    auto store_rows = [&](auto with_beta_t) {
-        constexpr bool WITH_BETA = decltype(with_beta_t)::value;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-#ifdef CTC_EXP_NOSTORE
-                    if (roff[i][r] != kNoOffset && coff[j] != kNoOffset && acc[i][j][r] == (T)1.2345e30) {
-#else
-                    if (roff[i][r] != kNoOffset && coff[j] != kNoOffset) {
-#endif
-                        T *dst = C + roff[i][r] + coff[j];
-                        T v = alpha * acc[i][j][r];
-                        if (WITH_BETA) v += beta * *dst;
-                        *dst = v;
-                    }
-                }
-            }
-        }
-    };
-    // Same with 16-byte stores (see Traits::cvec): half (f64) or a quarter (f32) of the store
-    // instructions, which is what bounds the epilogue of contractions with a short K.
-    // STREAM: C does not fit the Infinity Cache, so its lines are stored with the non-temporal hint and
-    // leave the caches to the operand panels (config-4 contraction with |C| = 32.8 GB: 41.4 -> 47.7 TFLOP/s).
-    auto store_rows_vec = [&](auto with_beta_t, auto stream_t) {
-        constexpr bool WITH_BETA = decltype(with_beta_t)::value;
-        constexpr bool STREAM = decltype(stream_t)::value;
-        typedef typename Tr::vec_t vec_t;
-        int64_t cvoff[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) cvoff[j] = s_coff[BM + wn0 + 16 * j + (frow & ~(Tr::CV - 1))];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int s = 0; s < Tr::NCV; ++s) {
-                const int64_t rvoff = s_coff[wm0 + 16 * i + Tr::cvec_row(lane, s)];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    vec_t v = Tr::cvec(acc[i][j], lane, s) * alpha;
-#ifdef CTC_EXP_NOSTORE
-                    if (rvoff != kNoOffset && cvoff[j] != kNoOffset && v[0] == (T)1.2345e30) {
-#else
-                    if (rvoff != kNoOffset && cvoff[j] != kNoOffset) {
-#endif
-                        vec_t *dst = reinterpret_cast<vec_t *>(C + rvoff + cvoff[j]);
-                        if (WITH_BETA) v += *dst * beta;
-                        if (STREAM) __builtin_nontemporal_store(v, dst);
-                        else *dst = v;
-                    }
-                }
-            }
-        }
-    };
-    if (p.c_vec > 1) {
-        if (beta != (T)0) store_rows_vec(std::true_type(), std::false_type());
-        else if (p.c_stream) store_rows_vec(std::false_type(), std::true_type());
-        else store_rows_vec(std::false_type(), std::false_type());
-    } else {
-        if (beta == (T)0) store_rows(std::false_type());
-        else store_rows(std::true_type());
-    }
+    store_tile<T, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, sid, chunk);
 #ifdef CTC_CLOCK
     if (t == 0 && blockIdx.y == 0 && (blockIdx.x == 700 || blockIdx.x == 2500 || blockIdx.x == 4500)) {
         const unsigned long long dc = __builtin_readcyclecounter() - ck_core0, dr = __builtin_amdgcn_s_memrealtime() - ck_real0;
@@ -650,9 +562,16 @@ hipError_t dispatch(int dtype, int la, int lb, int bm, int bn, const GemmParams 
 
 }  // namespace
 
+hipError_t launch_splitk_fixup_f64(const GemmParams &p, int tail_tiles, hipStream_t stream)
+{
+    hipLaunchKernelGGL((splitk_fixup_kernel<double, 128, 128>), dim3((unsigned)(tail_tiles * (128 / 16))), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t schedule_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p, GemmSchedule *out)
 {
     if (dtype == 2) return schedule_gemm_bf16(layout_a, layout_b, bm, p, out);
+    if (dtype == 0 && dma_gemm_f64_supported(layout_a, layout_b, bm, bn, p)) return schedule_gemm_dma_f64(layout_a, layout_b, p, out);
     return dispatch(dtype, layout_a, layout_b, bm, bn, p, out, nullptr, nullptr, nullptr);
 }
 
@@ -660,6 +579,8 @@ hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, co
                        const GemmSchedule &schedule, void *workspace, hipStream_t stream)
 {
     if (dtype == 2) return launch_gemm_bf16(layout_a, layout_b, bm, p, schedule, workspace, stream);
+    if (dtype == 0 && dma_gemm_f64_supported(layout_a, layout_b, bm, bn, p))
+        return launch_gemm_dma_f64(layout_a, layout_b, p, schedule, workspace, stream);
     return dispatch(dtype, layout_a, layout_b, bm, bn, p, nullptr, &schedule, workspace, stream);
 }
 

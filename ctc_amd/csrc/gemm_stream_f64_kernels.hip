@@ -22,6 +22,7 @@
 // ka_stride / kb_stride); everything else takes the register-staged form or the classic kernel.
 #include "gemm_device.hpp"
 #include "kernels.hpp"
+#include "lds_dma.hpp"
 
 #include <atomic>
 #include <cstdio>
@@ -33,6 +34,7 @@ namespace ctc {
 namespace {
 
 using namespace gemm_detail;
+using namespace lds_dma;
 
 constexpr int kBM = 128, kBN = 64, kStages = 3;
 // Two geometries.  K-tile 32: one workgroup per CU (144 KB of operand stages), every layout.  K-tile 16:
@@ -58,51 +60,6 @@ template <int BK> struct Geom {
     // K-tiles of an item that carry the previous item's stores (K >= 64: at least that many K-tiles)
     static constexpr int kStoreTiles = 64 / BK;
 };
-
-__device__ __forceinline__ void dma16(const void *src, unsigned char *lds_wave_base)
-{
-    typedef __attribute__((address_space(1))) const void *gptr_t;
-    typedef __attribute__((address_space(3))) void *lptr_t;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
-}
-
-// LDS reads of the main loop are issued from inline assembly: the compiler makes every LDS load it can
-// see wait for ALL outstanding LDS-DMA transfers (it cannot tell that they target another stage), which
-// would drain the operand pipeline at every k-step.  The price: the compiler does not know these loads
-// are asynchronous either, so every value read this way passes through lds_wait() (an s_waitcnt that
-// names the value as an in/out operand) before its first use.
-__device__ __forceinline__ unsigned lds_addr(const void *p)
-{
-    typedef __attribute__((address_space(3))) const unsigned char *lptr_t;
-    return (unsigned)(uintptr_t)(lptr_t)p;
-}
-template <int OFF> __device__ __forceinline__ void lds_read64(double &d, unsigned addr)
-{
-    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-template <int OFF> __device__ __forceinline__ void lds_read64(int64_t &d, unsigned addr)
-{
-    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-template <typename V> __device__ __forceinline__ void lds_wait(V &a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
-// the same with up to N younger LDS reads still in flight (LDS reads return in order; the caller knows that
-// at least N were issued after the one that fills `a`)
-template <int N, typename V> __device__ __forceinline__ void lds_wait_but(V &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
-template <typename V> __device__ __forceinline__ void lds_wait(V &a, V &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void lds_wait(double &a0, double &a1, double &a2, double &a3, double &b0, double &b1)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1));
-}
-
-template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>());
-        static_for<I + 1, N>(f);
-    }
-}
 
 // DMA staging of one BR x 32 fp64 operand tile by 4 waves; NI instructions per wave per tile.
 // Address arithmetic is kept off the vector ALU (a wave that feeds the matrix pipe has about sixteen

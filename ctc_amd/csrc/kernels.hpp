@@ -37,6 +37,10 @@ struct GemmParams {
     // k_a[k] == k * ka_stride for every k (likewise k_b): the operand's k offsets need no table
     // (0: they do).  Set by the launcher from the plan.
     int64_t ka_stride = 0, kb_stride = 0;
+    // k8_affine != 0: K is a multiple of 8 and inside every aligned group of 8 the k offsets are affine,
+    // k_a[8 g + i] == k_a[8 g] + i * ka_in (likewise k_b, kb_in): a K-tile of 8 needs one table entry
+    int k8_affine = 0;
+    int64_t ka_in = 0, kb_in = 0;
 };
 
 struct GemmSchedule {
@@ -62,6 +66,15 @@ hipError_t launch_gemm_stream(int dtype, int layout_a, int layout_b, const GemmP
 // addition, even M and N and k offsets that are multiples of k (GemmParams::ka_stride / kb_stride).
 bool stream_gemm_f64_dma_supported(int layout_a, int layout_b, const GemmParams &p);
 hipError_t launch_gemm_stream_f64_dma(int layout_a, int layout_b, const GemmParams &p, hipStream_t stream);
+
+// fp64, 128 x 128 tiles, operands staged by LDS-DMA (gemm_dma_f64_kernels.hip); schedule_gemm / launch_gemm
+// route to it when dma_gemm_f64_supported says the launch qualifies (vector layouts, k8_affine).
+bool dma_gemm_f64_supported(int layout_a, int layout_b, int bm, int bn, const GemmParams &p);
+hipError_t schedule_gemm_dma_f64(int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out);
+hipError_t launch_gemm_dma_f64(int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
+                               void *workspace, hipStream_t stream);
+// the split-K fix-up pass of 128 x 128 fp64 tiles (gemm_kernels.hip); p carries the schedule
+hipError_t launch_splitk_fixup_f64(const GemmParams &p, int tail_tiles, hipStream_t stream);
 
 // bf16 operands and result, f32 accumulation (gemm_bf16_kernels.hip): square tiles, bm = 128 or 256
 // (256 only with 16-byte-vector layouts on both operands, otherwise 128 is used), K-tile 64;

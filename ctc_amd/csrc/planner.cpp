@@ -323,7 +323,20 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
     };
     p.ka_stride = affine(p.k_a);
     p.kb_stride = affine(p.k_b);
+    {
+        auto affine8 = [](const std::vector<int64_t> &tab, int64_t K, int64_t &step) {
+            if (K < 8 || K % 8 != 0) return false;
+            step = tab[1] - tab[0];
+            for (int64_t g = 0; g < K; g += 8)
+                for (int i = 1; i < 8; ++i)
+                    if (tab[g + i] != tab[g] + i * step) return false;
+            return true;
+        };
+        p.k8_affine = affine8(p.k_a, p.K, p.ka_in) && affine8(p.k_b, p.K, p.kb_in);
+    }
     build_table(p, p.ex_n, gb, p.N, p.col_b);
+    for (int64_t v : p.row_a) p.max_row_a = v > p.max_row_a ? v : p.max_row_a;
+    for (int64_t v : p.col_b) p.max_col_b = v > p.max_col_b ? v : p.max_col_b;
     build_table(p, p.ex_m, sc, p.M, p.row_c);
     build_table(p, p.ex_n, sc, p.N, p.col_c);
     build_table(p, p.ex_batch, ga, p.batch, p.bat_a);

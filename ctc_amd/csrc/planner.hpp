@@ -60,6 +60,13 @@ struct Plan {
     std::vector<int64_t> row_a, k_a, k_b, col_b, row_c, col_c, bat_a, bat_b, bat_c;
     // k_a[k] == k * ka_stride for every k (the contracted modes fuse into one stride); 0 when they do not
     int64_t ka_stride = 0, kb_stride = 0;
+    // k8_affine: K is a multiple of 8 and inside every aligned group of 8 contracted indices both k tables
+    // are affine with steps ka_in / kb_in (true when the fastest contracted mode's extent is a multiple
+    // of 8): a kernel that walks K in tiles of 8 needs one table entry per tile
+    bool k8_affine = false;
+    int64_t ka_in = 0, kb_in = 0;
+    // largest row offset of A / column offset of B (elements)
+    int64_t max_row_a = 0, max_col_b = 0;
 
     // Skinny path (M <= 16, K small, N large): memory-bound, no MFMA.  kSkinnySame:
     // B and C share their unit-stride N mode, vectors run along the fused N index and
