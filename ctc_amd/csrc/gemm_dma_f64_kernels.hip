@@ -114,6 +114,9 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
     const int wn0 = (wave % WN) * (TN * 16);
     const int frow = lane & 15;
     const int fk = lane >> 4;
+#ifdef CTC_CLOCK  // diagnostic build: shader clock while this workgroup runs = core-clock ticks / 100 MHz ticks
+    const unsigned long long ck_core0 = __builtin_readcyclecounter(), ck_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // block -> tile, as in gemm_kernel: XCD-contiguous runs of tile ids, groups of tile rows, the tiles of
     // the last round cut along K
@@ -194,16 +197,16 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
     k_fetch();
     k_wait();
     // instruction u (0, 1: A; 2, 3: B) of the requested tile into stage `stage`
-    auto issue = [&](int u, unsigned char *stage, int64_t ka, int64_t kb) {
+    auto issue = [&](int u, unsigned stage, int64_t ka, int64_t kb) {  // stage: LDS address
         const int j = u & 1;
-        if (u < 2) dma16(A + Operand<LA>::uniform(ka, p.ka_in, wave, j) + oa.off[j], stage + (2 * wave + j) * 1024);
-        else dma16(B + Operand<LB>::uniform(kb, p.kb_in, wave, j) + ob.off[j], stage + kOpBytes + (2 * wave + j) * 1024);
+        if (u < 2) dma16_split(A + Operand<LA>::uniform(ka, p.ka_in, wave, j), oa.off[j], stage + (2 * wave + j) * 1024);
+        else dma16_split(B + Operand<LB>::uniform(kb, p.kb_in, wave, j), ob.off[j], stage + kOpBytes + (2 * wave + j) * 1024);
     };
     __syncthreads();  // s_coff is written; no DMA is in flight yet
 #pragma unroll
     for (int s = 0; s < kStages - 1; ++s) {
 #pragma unroll
-        for (int u = 0; u < NDMA; ++u) issue(u, smem + s * kStageBytes, ka_next, kb_next);
+        for (int u = 0; u < NDMA; ++u) issue(u, smem_lds + s * kStageBytes, ka_next, kb_next);
         advance();
         k_wait();
     }
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
     //   k-step 1: first fragment reads of K-tile +1; the k offsets of the tile requested next.
     auto tile_step = [&](auto stage_t) {
         constexpr int S = decltype(stage_t)::value, SN = (S + 1) % kStages, SL = (S + kStages - 1) % kStages;
-        unsigned char *ld = smem + SL * kStageBytes;
+        const unsigned ld = smem_lds + SL * kStageBytes;
         frags_wait(I0());
         k_wait();  // requested a k-step ago, and the fragment wait has covered it
         const int64_t ka = ka_next, kb = kb_next;
@@ -284,6 +287,12 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
     frags_wait(I0());
 
     store_tile<double, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, sid, chunk);
+#ifdef CTC_CLOCK
+    if (t == 0 && blockIdx.y == 0 && (blockIdx.x == 700 || blockIdx.x == 2500 || blockIdx.x == 4500)) {
+        const unsigned long long dc = __builtin_readcyclecounter() - ck_core0, dr = __builtin_amdgcn_s_memrealtime() - ck_real0;
+        printf("[clock] block %d: %llu core ticks in %llu x 10 ns -> %.3f GHz\n", (int)blockIdx.x, dc, dr, (double)dc / (10.0 * (double)dr));
+    }
+#endif
 }
 
 template <int LA, int LB> int resident_slots()

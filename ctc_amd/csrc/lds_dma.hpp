@@ -25,6 +25,21 @@ __device__ __forceinline__ void dma16(const void *src, unsigned char *lds_wave_b
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// The same with the address split the way the instruction takes it: a wave-uniform 64-bit base in scalar
+// registers plus a 32-bit byte offset per lane, so that no vector-ALU instruction forms the address.  Issued
+// from assembly (the compiler, given a pointer, adds the two parts on the vector ALU); lds_wave_base is the
+// LDS byte address the wave's 1 KB goes to.  The compiler does not count these transfers in its own
+// s_waitcnt bookkeeping: the caller waits for them explicitly.  M0 is overwritten (it cannot be named as a
+// clobber: the compiler reserves it), so a kernel that uses this must have no other use of M0 alive across
+// the call; the kernels here have none (their only M0 users are these transfers).
+__device__ __forceinline__ void dma16_split(const void *uniform_base, unsigned lane_offset, unsigned lds_wave_base)
+{
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_offset), "s"(uniform_base), "s"(lds_wave_base)
+                 : "memory");
+}
+
 __device__ __forceinline__ unsigned lds_addr(const void *p)
 {
     typedef __attribute__((address_space(3))) const unsigned char *lptr_t;
