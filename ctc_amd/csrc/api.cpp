@@ -253,6 +253,12 @@ int initial_stream_mode()
 std::atomic<int> g_stream_mode{initial_stream_mode()};
 std::atomic<int64_t> g_launches_classic{0}, g_launches_stream{0}, g_launches_stream_dma{0};  // since load, for tests
 std::atomic<int> g_stream_f64_dma{1};  // 0: fp64 takes the register-staged persistent kernel too (A/B runs)
+std::atomic<int> g_dma_gemm{1};        // 0: tiled GEMMs never take the LDS-DMA kernel (A/B runs)
+std::atomic<int64_t> g_launches_dma_gemm{0};
+bool plan_k8_affine(const ctc::Plan &p)
+{
+    return g_dma_gemm.load() != 0 && p.k8_affine && p.max_row_a < (int64_t(1) << 28) && p.max_col_b < (int64_t(1) << 28);
+}
 std::atomic<int64_t> g_stream_max_k{getenv("CTC_TC_STREAM_MAX_K") ? atoll(getenv("CTC_TC_STREAM_MAX_K")) : kStreamMaxK};
 
 // The split-K workspace a tiled-GEMM plan can ask for on the current device: the largest over the
@@ -263,7 +269,7 @@ size_t worst_splitk_bytes(const ctc::Plan &p)
     ctc::GemmParams g;
     g.M = p.M; g.N = p.N; g.K = p.K;
     g.batch = (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch);
-    g.k8_affine = (p.k8_affine && p.max_row_a < (int64_t(1) << 28) && p.max_col_b < (int64_t(1) << 28)) ? 1 : 0;
+    g.k8_affine = plan_k8_affine(p) ? 1 : 0;
     g.ka_in = p.ka_in;
     g.kb_in = p.kb_in;
     size_t worst = 0;
@@ -335,7 +341,7 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     g.c_stream = (double)p.M * (double)p.N * (double)p.batch * (double)ctc::dtype_size(p.dtype) > 256.0 * 1048576.0;
 
     // one table entry per K-tile of 8 and 32-bit lane offsets: what the LDS-DMA kernel needs
-    g.k8_affine = (p.k8_affine && p.max_row_a < (int64_t(1) << 28) && p.max_col_b < (int64_t(1) << 28)) ? 1 : 0;
+    g.k8_affine = plan_k8_affine(p) ? 1 : 0;
     g.ka_in = p.ka_in;
     g.kb_in = p.kb_in;
 
@@ -364,7 +370,8 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
         }
     }
 
-    g_launches_classic.fetch_add(1);
+    if (p.dtype == ctc::kF64 && ctc::dma_gemm_f64_supported(la, lb, p.tile.bm, p.tile.bn, g)) g_launches_dma_gemm.fetch_add(1);
+    else g_launches_classic.fetch_add(1);
     ctc::GemmSchedule sch;
     hipError_t e = ctc::schedule_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, &sch);
     if (e != hipSuccess) return fail_hip(e, "contraction schedule");
@@ -493,6 +500,10 @@ int ctc_tc_set_option(const char *name, int64_t value)
         g_stream_mode.store((int)value);
         return CTC_TC_OK;
     }
+    if (n == "dma_gemm") {
+        g_dma_gemm.store(value != 0);
+        return CTC_TC_OK;
+    }
     if (n == "stream_f64_dma") {
         g_stream_f64_dma.store(value != 0);
         return CTC_TC_OK;
@@ -511,6 +522,8 @@ int64_t ctc_tc_get_option(const char *name)
     if (n == "stream_mode") return g_stream_mode.load();
     if (n == "stream_max_k") return g_stream_max_k.load();
     if (n == "stream_f64_dma") return g_stream_f64_dma.load();
+    if (n == "dma_gemm") return g_dma_gemm.load();
+    if (n == "launches_dma_gemm") return g_launches_dma_gemm.load();
     if (n == "launches_classic") return g_launches_classic.load();
     if (n == "launches_stream") return g_launches_stream.load();
     if (n == "launches_stream_f64_dma") return g_launches_stream_dma.load();

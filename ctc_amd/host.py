@@ -274,7 +274,8 @@ def set_option(name, value):
 
 
 def get_option(name):
-    """Value of a knob, or of a launch counter ("launches_classic", "launches_stream", "launches_stream_f64_dma")."""
+    """Value of a knob, or of a launch counter ("launches_classic", "launches_dma_gemm", "launches_stream",
+    "launches_stream_f64_dma")."""
     return int(check(_lib.load().ctc_tc_get_option(name.encode())))
 
 

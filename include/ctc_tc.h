@@ -128,12 +128,16 @@ const char *ctc_tc_last_error(void);
  *                   batch entry, K > 32);
  *   "stream_max_k"  largest K the automatic choice sends to the persistent kernel (default 128; fp32: at most 96);
  *   "stream_f64_dma" 1 (default): fp64 launches that qualify (even M and N, one stride per operand along
- *                   K) take the persistent kernel's LDS-DMA form; 0: its register-staged form.
+ *                   K) take the persistent kernel's LDS-DMA form; 0: its register-staged form;
+ *   "dma_gemm"      1 (default): fp64 one-tile-per-workgroup launches whose operands both have a
+ *                   16-byte-vector layout and whose k offsets are affine inside every aligned group of 8
+ *                   (K a multiple of 8) stage their operands by LDS-DMA; 0: always through registers.
  * No reference counterpart.
  */
 int ctc_tc_set_option(const char *name, int64_t value);
 /* Value of a knob above, or of a read-only counter of tiled-GEMM launches since the library was loaded:
- * "launches_classic", "launches_stream" (persistent, register-staged), "launches_stream_f64_dma".
+ * "launches_classic" (register-staged), "launches_dma_gemm", "launches_stream" (persistent,
+ * register-staged), "launches_stream_f64_dma".
  * Negative ctc_tc_status for an unknown name. */
 int64_t ctc_tc_get_option(const char *name);
 

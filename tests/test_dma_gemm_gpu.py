@@ -1,0 +1,139 @@
+"""The fp64 GEMM kernel that stages its operands by LDS-DMA (128 x 128 tiles, K-tiles of 8) against the
+CPU oracle and against the register-staged kernel, through the C ABI.  Both kernels add the products of
+their K-tiles in k order into the same accumulators, so the two agree to the parity tolerance (1e-12 of
+max |C|); index and table outputs are the planner's and are compared bit for bit elsewhere."""
+import numpy as np
+import pytest
+import torch
+
+import ctc_amd
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+NAMES = ("launches_classic", "launches_dma_gemm", "launches_stream", "launches_stream_f64_dma")
+
+
+def _delta(fn):
+    before = [ctc_amd.get_option(n) for n in NAMES]
+    fn()
+    return tuple(ctc_amd.get_option(n) - b for n, b in zip(NAMES, before))
+
+
+def _operands(oracle, spec, ext, dev):
+    ins, outm = spec.split("->")
+    la, lb = ins.split(",")
+    A = oracle.fill(int(np.prod([ext[c] for c in la])), 0xC7C0A, 0)
+    B = oracle.fill(int(np.prod([ext[c] for c in lb])), 0xC7C0B, 0)
+    return A, B, int(np.prod([ext[c] for c in outm])), torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+
+
+def _check(got, want):
+    err = np.abs(got - want).max()
+    assert err <= TOL * np.abs(want).max(), "max err %.3e vs scale %.3e" % (err, np.abs(want).max())
+
+
+CASES = [
+    # every operand layout pair, ragged edges in M and N, one K-tile to many (the request ring wraps when
+    # a workgroup has fewer than three K-tiles)
+    ("nn_kmajor_outer", "ak,kb->ab", dict(a=2500, b=2600, k=64)),
+    ("nt_kmajor_kmajor", "ak,bk->ab", dict(a=2562, b=2430, k=40)),
+    ("tn_outer_outer", "ka,kb->ab", dict(a=2600, b=2498, k=56)),
+    ("tt_outer_kmajor", "ka,bk->ab", dict(a=2434, b=2690, k=72)),
+    ("one_k_tile", "ak,kb->ab", dict(a=2500, b=2600, k=8)),
+    ("two_k_tiles", "ka,kb->ab", dict(a=2500, b=2600, k=16)),
+    ("three_k_tiles", "ak,bk->ab", dict(a=2500, b=2600, k=24)),
+    ("five_k_tiles", "ka,bk->ab", dict(a=2500, b=2600, k=40)),
+    # contracted modes that do not fuse: affine only inside groups of 8 (the headline contraction's shape)
+    ("ccsd_three_by_24", "aeim,ebmj->abij", dict(a=52, b=50, i=50, j=52, e=3, m=24)),
+    ("ccsd_uneven", "aeim,ebmj->abij", dict(a=50, b=44, i=52, j=60, e=5, m=16)),
+    ("ccsd_other_layouts", "eaim,jbem->abij", dict(a=48, b=50, i=54, j=52, e=3, m=8)),
+    # the last, partly filled round of tiles is cut along K: partial sums through the workspace
+    ("split_k_tail", "ak,kb->ab", dict(a=1024, b=1152, k=4096)),
+    ("split_k_everything", "ka,bk->ab", dict(a=256, b=384, k=32768)),
+    # batch entries run as grid.y
+    ("batched", "zak,zkb->zab", dict(z=3, a=1500, b=1400, k=32)),
+    ("rank6", "adij,bcdk->abcijk", dict(a=6, b=20, c=20, i=20, j=22, k=8, d=24)),
+]
+
+
+@pytest.mark.parametrize("name,spec,ext", CASES, ids=[c[0] for c in CASES])
+def test_dma_gemm_against_oracle_and_register_staged(cuda, oracle, name, spec, ext):
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, cuda)
+    plan = ctc_amd.Plan(spec, ext, "f64")
+    s = plan.summary()
+    assert s["kernel"] == "mfma_gemm" and s["tile"][:2] == (128, 128), s
+    assert s["layout_a"] != "scalar" and s["layout_b"] != "scalar", s
+    ctc_amd.set_option("stream_mode", 1)  # the persistent kernel is another test's business
+    try:
+        dC = torch.full((n_out,), float("nan"), dtype=torch.float64, device=cuda)
+        took = _delta(lambda: plan.execute(dA, dB, dC, alpha=1.25))
+        assert took == (0, 1, 0, 0), took
+        want = oracle.contract(spec, ext, A, B, alpha=1.25, dtype=0)
+        got = dC.cpu().numpy()
+        assert not np.isnan(got).any()  # every element of C was stored
+        _check(got, want)
+        # beta != 0 on top of the first result, on both kernels
+        want2 = 0.5 * want + 0.75 * want / 1.25
+        plan.execute(dA, dB, dC, alpha=0.75, beta=0.5)
+        _check(dC.cpu().numpy(), want2)
+        ctc_amd.set_option("dma_gemm", 0)
+        dC2 = torch.full((n_out,), float("nan"), dtype=torch.float64, device=cuda)
+        took = _delta(lambda: plan.execute(dA, dB, dC2, alpha=1.25))
+        assert took == (1, 0, 0, 0), took
+        _check(dC2.cpu().numpy(), want)
+    finally:
+        ctc_amd.set_option("dma_gemm", 1)
+        ctc_amd.set_option("stream_mode", 0)
+
+
+def test_which_launches_take_the_dma_kernel(cuda):
+    x = torch.zeros(4096 * 4096, dtype=torch.float64, device=cuda)
+    c = torch.zeros(4096 * 4096, dtype=torch.float64, device=cuda)
+    run = lambda spec, ext, a=x: lambda: ctc_amd.Plan(spec, ext, "f64").execute(a, x, c)  # noqa: E731
+    big = dict(a=4096, b=4096)
+    assert _delta(run("ak,kb->ab", dict(big, k=256))) == (0, 1, 0, 0)
+    assert _delta(run("ak,kb->ab", dict(big, k=260))) == (1, 0, 0, 0)                 # K not a multiple of 8
+    assert _delta(run("aef,feb->ab", dict(big, e=4, f=12))) == (1, 0, 0, 0)            # groups of 8 straddle a mode
+    assert _delta(run("aef,feb->ab", dict(big, e=16, f=8))) == (0, 1, 0, 0)            # they do not
+    assert _delta(run("ak,kb->ab", dict(a=512, b=512, k=256))) == (1, 0, 0, 0)         # small tile
+    assert _delta(run("ak,kb->ab", dict(big, k=256), x[1:])) == (1, 0, 0, 0)           # unaligned base: element loads
+    f32 = torch.zeros(4096 * 256, dtype=torch.float32, device=cuda)
+    c32 = torch.zeros(4096 * 4096, dtype=torch.float32, device=cuda)
+    assert _delta(lambda: ctc_amd.Plan("ak,kb->ab", dict(big, k=256), "f32").execute(f32, f32, c32)) == (1, 0, 0, 0)
+    ctc_amd.set_option("dma_gemm", 0)
+    try:
+        assert _delta(run("ak,kb->ab", dict(big, k=256))) == (1, 0, 0, 0)
+    finally:
+        ctc_amd.set_option("dma_gemm", 1)
+
+
+def test_headline_contraction_at_extent_64_properties(cuda, oracle):
+    """abij = aeim,ebmj at extent 64 (2 * 64^6 flops: too big for the oracle in a test): the LDS-DMA kernel
+    and the register-staged kernel must agree to 1e-12, and slabs C[a0, b0, :, :] are recomputed by the
+    oracle from the operand slices they depend on."""
+    n = 64
+    spec, ext = "aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n)
+    dA = torch.empty(n ** 4, dtype=torch.float64, device=cuda)
+    dB = torch.empty(n ** 4, dtype=torch.float64, device=cuda)
+    ctc_amd.fill(dA, 0xC7C0A)
+    ctc_amd.fill(dB, 0xC7C0B)
+    plan = ctc_amd.Plan(spec, ext, "f64")
+    dC = torch.full((n ** 4,), float("nan"), dtype=torch.float64, device=cuda)
+    assert _delta(lambda: plan.execute(dA, dB, dC)) == (0, 1, 0, 0)
+    ctc_amd.set_option("dma_gemm", 0)
+    try:
+        dC2 = torch.full((n ** 4,), float("nan"), dtype=torch.float64, device=cuda)
+        plan.execute(dA, dB, dC2)
+    finally:
+        ctc_amd.set_option("dma_gemm", 1)
+    scale = float(dC2.abs().max())
+    assert float((dC - dC2).abs().max()) <= TOL * scale
+    A = dA.cpu().numpy().reshape(n, n, n, n)
+    B = dB.cpu().numpy().reshape(n, n, n, n)
+    C = dC.cpu().numpy().reshape(n, n, n, n)
+    for a0, b0 in ((0, 0), (17, 63), (63, 5)):
+        sub = dict(a=1, b=1, i=n, j=n, e=n, m=n)
+        want = oracle.contract(spec, sub, np.ascontiguousarray(A[a0:a0 + 1]).reshape(-1),
+                               np.ascontiguousarray(B[:, b0:b0 + 1]).reshape(-1), dtype=0).reshape(n, n)
+        assert np.abs(C[a0, b0] - want).max() <= TOL * np.abs(want).max()

@@ -81,10 +81,11 @@ def test_persistent_kernel_against_oracle(cuda, oracle, forced_stream, name, spe
 def test_which_kernel_runs(cuda, oracle):
     """Routing: the counters say which tiled-GEMM kernel a launch took."""
     def delta(fn):
-        names = ("launches_classic", "launches_stream", "launches_stream_f64_dma")
+        names = ("launches_classic", "launches_dma_gemm", "launches_stream", "launches_stream_f64_dma")
         before = [ctc_amd.get_option(n) for n in names]
         fn()
-        return tuple(ctc_amd.get_option(n) - b for n, b in zip(names, before))
+        d = [ctc_amd.get_option(n) - b for n, b in zip(names, before)]
+        return (d[0] + d[1], d[2], d[3])  # one-tile-per-workgroup (either staging), persistent, persistent LDS-DMA
     x = torch.zeros(4096 * 96, dtype=torch.float64, device=cuda)
     c = torch.zeros(4096 * 4096, dtype=torch.float64, device=cuda)
     run = lambda spec, ext, **kw: lambda: ctc_amd.Plan(spec, ext, "f64").execute(x, x, c, **kw)  # noqa: E731
