@@ -35,6 +35,7 @@ SEED_A, SEED_B = 0xC7C0A, 0xC7C0B
 # fp64 matrix peak of MI355X, dense, public datasheet value (256 CUs x 4 SIMDs x
 # 32 flop/clk x 2.4 GHz); the measured microarchitecture guide lists no fp64 row.
 PEAK_FP64_MFMA_TFLOPS = 78.6
+TRAFFIC_FILE = "r02b_bench_traffic.json"  # counter passes of the kernel the bench currently runs
 
 
 def cpu_baseline(extent, threads):
@@ -86,12 +87,12 @@ def verify_slabs(dC, n, first_a, a_idx, b_list):
 def measured_traffic(extent, kernel_summary):
     """HBM-side bytes per launch from the committed counter passes (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE, one pass each, tools/pmc_traffic.sh); None when they do not cover this run."""
-    path = os.path.join(ROOT, "profiles", "r01c_bench_traffic.json")
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if extent != 96 or not os.path.exists(path):
         return None
     with open(path) as f:
         t = json.load(f)
-    if "128, 128" not in t.get("kernel", "") or tuple(kernel_summary["tile"][:2]) != (128, 128):
+    if kernel_summary["kernel_name"].split("<")[0] not in t.get("kernel", "") or tuple(kernel_summary["tile"][:2]) != (128, 128):
         return None
     return t["per_launch_bytes"]["total_corrected"]
 
@@ -294,6 +295,7 @@ def main():
     for _ in range(args.warmup):
         plan.execute(A, B, C)
     barrier()
+    launches_dma_before = ctc_amd.get_option("launches_dma_gemm")
     t0 = time.perf_counter()
     # K launches on torch's current stream, bracketed by HIP events on that same stream
     kernel_ms = plan.time(A, B, C, warmup=0, iters=args.steps)
@@ -335,6 +337,9 @@ def main():
 
     if rank == 0:
         s = plan.summary()
+        # which tiled-GEMM kernel the timed launches took (the library counts them)
+        s["kernel_name"] = ("gemm_dma_f64_kernel<%d, %d>" % (s["layout_a"] != "k_vec", s["layout_b"] != "k_vec")
+                            if ctc_amd.get_option("launches_dma_gemm") > launches_dma_before else "gemm_kernel<double>")
         achieved = flops_rank / (kernel_ms * 1e-3) * 1e-12
         out = {
             "metric": "achieved TFLOP/s per contraction (fp64, C[a,b,i,j]=A[a,e,i,m]*B[e,b,m,j])",
@@ -353,7 +358,7 @@ def main():
                 "workload": "BASELINE configs[1]: abij=aeim,ebmj fp64, all extents %d%s" % (
                     n, "" if world == 1 else ", free index a sharded: extent %d over %d GPUs" % (n * world, world)),
                 "gemm_view": {"M": s["M"], "N": s["N"], "K": s["K"]},
-                "tile": list(s["tile"]), "layout_a": s["layout_a"], "layout_b": s["layout_b"],
+                "tile": [128, 128, 8] if s["kernel_name"].startswith("gemm_dma") else list(s["tile"]), "layout_a": s["layout_a"], "layout_b": s["layout_b"],
                 "flops_per_step": flops_job,
                 "pct_of_fp64_mfma_peak": round(100.0 * value / (PEAK_FP64_MFMA_TFLOPS * world), 2),
                 "variants": variants,
@@ -365,9 +370,9 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
                 "traffic": measured_traffic(n, s) if world == 1 else None,
-                "traffic_unit": "bytes per launch at the L2's memory side (separate counter passes, profiles/r01c_bench_traffic.json)",
+                "traffic_unit": "bytes per launch at the L2's memory side (separate counter passes, profiles/%s)" % TRAFFIC_FILE,
                 "algorithmic_bytes_per_launch": 3 * 8 * n ** 4,
-                "kernel": "gemm_kernel<double>",
+                "kernel": s["kernel_name"],
                 "kernel_ms": round(kernel_ms, 4),
                 "algorithmic_flops_per_launch": flops_rank,
             },

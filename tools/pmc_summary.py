@@ -12,7 +12,7 @@ for d in sys.argv[1:]:
                 "select kernel_name, counter_name, value, duration from counters_collection"):
             if "gemm" not in name:
                 continue
-            k = "stream" if "gemm_stream" in name else ("fixup" if "fixup" in name else "classic")
+            k = "stream" if "gemm_stream" in name else ("fixup" if "fixup" in name else ("lds_dma" if "gemm_dma" in name else "classic"))
             a = acc[(k, counter)]
             a[0] += float(value)
             a[1] += 1

@@ -19,9 +19,10 @@ def counters(directory, counter):
                 continue
             if "splitk_fixup" in name:
                 out["fixup"].append(float(value))
-            elif "gemm_kernel" in name:
+            elif "gemm_kernel" in name or "gemm_dma_f64_kernel" in name:
                 out["gemm"].append(float(value))
-                out["gemm_name"] = name[name.index("gemm_kernel"):].split("(")[0]
+                key = "gemm_dma_f64_kernel" if "gemm_dma_f64_kernel" in name else "gemm_kernel"
+                out["gemm_name"] = name[name.index(key):].split("(")[0]
             elif "copyBuffer" in name:
                 out["copy"].append(float(value))
     return out
