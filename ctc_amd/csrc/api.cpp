@@ -270,6 +270,7 @@ size_t worst_splitk_bytes(const ctc::Plan &p)
     g.M = p.M; g.N = p.N; g.K = p.K;
     g.batch = (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch);
     g.k8_affine = plan_k8_affine(p) ? 1 : 0;
+    g.k16_affine = (g.k8_affine && p.k16_affine) ? 1 : 0;
     g.ka_in = p.ka_in;
     g.kb_in = p.kb_in;
     size_t worst = 0;
@@ -342,6 +343,7 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
 
     // one table entry per K-tile of 8 and 32-bit lane offsets: what the LDS-DMA kernel needs
     g.k8_affine = plan_k8_affine(p) ? 1 : 0;
+    g.k16_affine = (g.k8_affine && p.k16_affine) ? 1 : 0;
     g.ka_in = p.ka_in;
     g.kb_in = p.kb_in;
 
@@ -370,7 +372,7 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
         }
     }
 
-    if (p.dtype == ctc::kF64 && ctc::dma_gemm_f64_supported(la, lb, p.tile.bm, p.tile.bn, g)) g_launches_dma_gemm.fetch_add(1);
+    if (ctc::dma_gemm_supported(p.dtype, la, lb, p.tile.bm, p.tile.bn, g)) g_launches_dma_gemm.fetch_add(1);
     else g_launches_classic.fetch_add(1);
     ctc::GemmSchedule sch;
     hipError_t e = ctc::schedule_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, &sch);

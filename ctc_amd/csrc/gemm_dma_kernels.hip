@@ -1,24 +1,26 @@
-// fp64 MFMA GEMM, one 128 x 128 tile of C per workgroup as in gemm_kernels.hip, with the operands staged
-// global -> LDS by LDS-DMA (global_load_lds_dwordx4) instead of through registers:
+// fp64 / fp32 MFMA GEMM, one 128 x 128 tile of C per workgroup as in gemm_kernels.hip, with the operands
+// staged global -> LDS by LDS-DMA (global_load_lds_dwordx4) instead of through registers:
 //   - the waves hold no staging registers and execute no LDS writes; per K-tile a wave issues four DMA
 //     instructions whose addresses are one 32-bit lane offset (fixed for the whole tile of C) on top of a
 //     wave-uniform 64-bit base, so staging costs the vector ALU nothing.  On MI355X the fp64 MFMA shares the
 //     vector ALU, and the register-staged kernel spends about three vector instructions per MFMA there;
-//   - K-tiles of 8 in a ring of four 16 KB stages (64 KB: two workgroups per CU): during K-tile t the DMA of
+//   - K-tiles of 64 bytes a row (8 fp64 / 16 fp32 contracted elements: two / four k-steps of MFMAs) in a
+//     ring of four 16 KB stages (64 KB: two workgroups per CU): during K-tile t the DMA of
 //     K-tile t + 3 is issued, the one of t + 1 is awaited (counted s_waitcnt: the memory counter retires in
 //     order) just before the single barrier of the tile;
 //   - a DMA instruction writes 1 KB of consecutive LDS (16 bytes per lane), so bank conflicts are removed by
 //     choosing WHICH 16-byte chunk a lane fetches instead of by padding:
-//       K-major operand (unit stride along K):   image [row][8 k] (64-byte rows), chunk c of row r stored at
+//       K-major operand (unit stride along K):   image [row][64 bytes of k], chunk c of row r stored at
 //           chunk position c ^ ((r >> 2) & 3);
-//       outer-major operand (unit stride along the rows): image [k][128 rows], chunk c (rows 2c, 2c + 1) of
-//           line k stored at position c ^ ((k & 1) << 3);
-//   - fragment reads are inline-assembly ds_read_b64 with the stage, the row block and the k-step in the
-//     instruction's offset field (the K-tile loop is unrolled over the four stages), two address registers
-//     per operand.
-// Needs: both operands in a 16-byte-vector layout, K a multiple of 8, k offsets that are affine inside every
-// aligned group of 8 (GemmParams::k8_affine; e.g. every contracted mode's extent a multiple of 8, or one
-// contracted mode), row / column offsets below 2^28 elements.  Everything else takes gemm_kernels.hip.
+//       outer-major operand (unit stride along the rows): image [k][128 rows]; fp64: chunk c (rows 2c, 2c + 1)
+//           of line k stored at position c ^ ((k & 1) << 3); fp32: chunk c (rows 4c .. 4c + 3) at c ^ ((k & 3) << 2);
+//   - fragment reads are inline-assembly ds_read_b64 / ds_read_b32 with the stage, the row block and the
+//     k-step in the instruction's offset field (the K-tile loop is unrolled over the four stages), two (fp64)
+//     or four (fp32) address registers per operand.
+// Needs: both operands in a 16-byte-vector layout, K a multiple of the K-tile, k offsets that are affine
+// inside every aligned group of that many (GemmParams::k8_affine / k16_affine; e.g. every contracted mode's
+// extent a multiple of it, or one contracted mode), row / column offsets below 2^28 elements.  Everything
+// else takes gemm_kernels.hip.
 // Tile order, split of the last round along K, epilogue: as there.
 #include "gemm_device.hpp"
 #include "kernels.hpp"
@@ -36,20 +38,35 @@ namespace {
 using namespace gemm_detail;
 using namespace lds_dma;
 
-constexpr int kBM = 128, kBN = 128, kBK = 8, kStages = 4;
-constexpr int kOpBytes = 128 * kBK * 8;    // one operand's tile image
+constexpr int kBM = 128, kBN = 128, kStages = 4;
+template <typename T> constexpr int tile_k() { return 64 / (int)sizeof(T); }
+constexpr int kOpBytes = 128 * 64;         // one operand's tile image
 constexpr int kStageBytes = 2 * kOpBytes;  // A image, then B image
+
+template <int OFF> __device__ __forceinline__ void lds_read(double &d, unsigned addr) { lds_read64<OFF>(d, addr); }
+template <int OFF> __device__ __forceinline__ void lds_read(float &d, unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <typename T> __device__ __forceinline__ void lds_wait8(T &a0, T &a1, T &a2, T &a3, T &b0, T &b1, T &b2, T &b3)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+}
 
 // What a lane fetches for its two DMA instructions per K-tile of one operand, and where a lane's MFMA
 // fragments sit in the operand's image.
-template <int LAY> struct Operand {
+template <typename T, int LAY> struct Operand {
     static constexpr bool KMAJ = (LAY != kLayOuterVec);
-    unsigned off[2];   // byte offset of the lane's 16 bytes from the wave-uniform base, instructions 0 and 1
-    unsigned frag[2];  // LDS byte addresses (stage 0, row block 0, k-step 0): KMAJ k-step 0 / 1, else even / odd row block
+    static constexpr int ES = (int)sizeof(T), V = 16 / ES;  // element size, elements per 16-byte chunk
+    static constexpr int NFRAG = (ES == 8) ? 2 : 4;
+    unsigned off[2];       // byte offset of the lane's 16 bytes from the wave-uniform base, instructions 0 and 1
+    unsigned frag[NFRAG];  // LDS byte addresses (stage 0): K-major: of k-step kk, row block 0; outer-major: of
+                           // row block b (fp64: b & 1 suffices), k-step 0
 
-    // tab: the operand's row (column) offsets, r0: first row of the tile, R: the operand's extent;
-    // instruction j of wave `wave` fills bytes [(2 wave + j) KB, + 1 KB) of the image
-    __device__ __forceinline__ void init_dma(const int64_t *__restrict__ tab, int64_t r0, int64_t R, int lane, int wave)
+    // tab: the operand's row (column) offsets, r0: first row of the tile, R: the operand's extent, kin: its
+    // step along k inside a K-tile; instruction j of wave `wave` fills bytes [(2 wave + j) KB, + 1 KB) of the image
+    __device__ __forceinline__ void init_dma(const int64_t *__restrict__ tab, int64_t r0, int64_t R, int64_t kin, int lane, int wave)
     {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -59,49 +76,72 @@ template <int LAY> struct Operand {
                 const int c = (lane & 3) ^ ((lane >> 4) & 3);
                 int64_t g = r0 + row;
                 if (g > R - 1) g = R - 1;  // rows past the extent repeat its last row: products never stored
-                off[j] = (unsigned)(tab[g] * 8 + c * 16);
-            } else {
+                off[j] = (unsigned)(tab[g] * ES + c * 16);
+            } else if (ES == 8) {
                 // one line per instruction (k = 2 wave + j, parity j), 64 chunks of two rows
                 const int c = lane ^ (j << 3);
                 int64_t g = r0 + 2 * c;
                 if (g > R - 2) g = R - 2;  // R is even: a pair never straddles the end
                 off[j] = (unsigned)(tab[g] * 8);
+            } else {
+                // two lines per instruction (k = 4 wave + 2 j + (lane >> 5)), 32 chunks of four rows each
+                const int kq = 2 * j + (lane >> 5);  // k & 3
+                const int c = (lane & 31) ^ (kq << 2);
+                int64_t g = r0 + 4 * c;
+                if (g > R - 4) g = R - 4;  // R is a multiple of 4
+                off[j] = (unsigned)(tab[g] * 4 + (lane >> 5) * kin * 4);
             }
         }
     }
     // w0: first row of the wave's part of the tile; image: LDS address of the operand's image in stage 0
     __device__ __forceinline__ void init_frag(unsigned image, int frow, int fk, int w0)
     {
-        if (KMAJ) {
+        if (KMAJ && ES == 8) {
             const int r2 = (frow >> 2) & 3;
             const int phys0 = ((fk >> 1) ^ (r2 & 1)) | ((r2 >> 1) << 1);
             const unsigned base = image + (w0 + frow) * 64 + phys0 * 16 + (fk & 1) * 8;
             frag[0] = base;
             frag[1] = base ^ 32;
-        } else {
+        } else if (KMAJ) {
+            // chunk kk of the row holds k = 4 kk .. 4 kk + 3
+            const int r2 = (frow >> 2) & 3;
+            const unsigned base = image + (w0 + frow) * 64 + r2 * 16 + fk * 4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) frag[kk] = base ^ (kk << 4);
+        } else if (ES == 8) {
             const int p = fk & 1;
             const unsigned base = image + fk * 1024 + ((w0 + frow) >> 1) * 16 + (frow & 1) * 8;
             frag[0] = base + 128 * p;
             frag[1] = base - 128 * p;
+        } else {
+            const unsigned base = image + fk * 512 + ((w0 >> 2) + (frow >> 2)) * 16 + (frow & 3) * 4;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) frag[b] = base + 64 * (b ^ fk);
         }
     }
-    template <int b, int kk> __device__ __forceinline__ unsigned frag_reg() const { return frag[KMAJ ? kk : (b & 1)]; }
-    template <int b, int kk> static constexpr int frag_imm() { return KMAJ ? b * 1024 : 128 * b + kk * 4096; }
+    template <int b, int kk> __device__ __forceinline__ unsigned frag_reg() const
+    {
+        return frag[KMAJ ? kk : (ES == 8 ? (b & 1) : b)];
+    }
+    template <int b, int kk> static constexpr int frag_imm()
+    {
+        return KMAJ ? b * 1024 : (ES == 8 ? 128 * b + kk * 4096 : kk * 2048);
+    }
     // wave-uniform byte offset of instruction j of the K-tile whose first k offset (elements) is kofs
     __device__ __forceinline__ static int64_t uniform(int64_t kofs, int64_t kin, int wave, int j)
     {
-        return KMAJ ? kofs * 8 : (kofs + (int64_t)(2 * wave + j) * kin) * 8;
+        return KMAJ ? kofs * ES : (kofs + (int64_t)((2 * wave + j) * (ES == 8 ? 1 : 2)) * kin) * ES;
     }
 };
 
-template <int LA, int LB>
-__global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p)
+template <typename T, int LA, int LB>
+__global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
 {
-    constexpr int BM = kBM, BN = kBN, BK = kBK, WN = 2;
-    constexpr int TM = 4, TN = 4, NMFMA = TM * TN;
-    static_assert(BK == 8, "two k-steps per K-tile");
-    typedef Traits<double> Tr;
-    typedef Tr::acc_t acc_t;
+    constexpr int BM = kBM, BN = kBN, BK = tile_k<T>(), WN = 2;
+    constexpr int TM = 4, TN = 4, NMFMA = TM * TN, KSTEPS = BK / 4;
+    static_assert(KSTEPS >= 2 && KSTEPS % 2 == 0, "fragment slots alternate per k-step");
+    typedef Traits<T> Tr;
+    typedef typename Tr::acc_t acc_t;
     constexpr int NDMA = 4;  // per wave per K-tile
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes];
@@ -144,9 +184,9 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
     const int64_t n0 = (int64_t)tn * BN;
     const int bz = blockIdx.y;
 
-    const char *A = reinterpret_cast<const char *>(static_cast<const double *>(p.A) + p.bat_a[bz]);
-    const char *B = reinterpret_cast<const char *>(static_cast<const double *>(p.B) + p.bat_b[bz]);
-    double *C = static_cast<double *>(p.C) + p.bat_c[bz];
+    const char *A = reinterpret_cast<const char *>(static_cast<const T *>(p.A) + p.bat_a[bz]);
+    const char *B = reinterpret_cast<const char *>(static_cast<const T *>(p.B) + p.bat_b[bz]);
+    T *C = static_cast<T *>(p.C) + p.bat_c[bz];
 
     const int nk_total = (int)(p.K / BK);
     const int kt_first = partial ? (int)((int64_t)chunk * nk_total / p.split) : 0;
@@ -164,10 +204,12 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
             s_coff[idx] = ok ? off : kNoOffset;
         }
     }
-    Operand<LA> oa;
-    Operand<LB> ob;
-    oa.init_dma(p.row_a, m0, p.M, lane, wave);
-    ob.init_dma(p.col_b, n0, p.N, lane, wave);
+    typedef Operand<T, LA> OA;
+    typedef Operand<T, LB> OB;
+    OA oa;
+    OB ob;
+    oa.init_dma(p.row_a, m0, p.M, p.ka_in, lane, wave);
+    ob.init_dma(p.col_b, n0, p.N, p.kb_in, lane, wave);
     const unsigned smem_lds = lds_addr(smem);
     oa.init_frag(smem_lds, frow, fk, wm0);
     ob.init_frag(smem_lds + kOpBytes, frow, fk, wn0);
@@ -199,8 +241,8 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
     // instruction u (0, 1: A; 2, 3: B) of the requested tile into stage `stage`
     auto issue = [&](int u, unsigned stage, int64_t ka, int64_t kb) {  // stage: LDS address
         const int j = u & 1;
-        if (u < 2) dma16_split(A + Operand<LA>::uniform(ka, p.ka_in, wave, j), oa.off[j], stage + (2 * wave + j) * 1024);
-        else dma16_split(B + Operand<LB>::uniform(kb, p.kb_in, wave, j), ob.off[j], stage + kOpBytes + (2 * wave + j) * 1024);
+        if (u < 2) dma16_split(A + OA::uniform(ka, p.ka_in, wave, j), oa.off[j], stage + (2 * wave + j) * 1024);
+        else dma16_split(B + OB::uniform(kb, p.kb_in, wave, j), ob.off[j], stage + kOpBytes + (2 * wave + j) * 1024);
     };
     __syncthreads();  // s_coff is written; no DMA is in flight yet
 #pragma unroll
@@ -213,23 +255,23 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");  // K-tile 0 has landed
     __builtin_amdgcn_s_barrier();
 
-    double fa[2][TM], fb[2][TN];
+    T fa[2][TM], fb[2][TN];
     // fragments of k-step KK of stage S into slot SLOT; asynchronous (frags_wait)
     auto read_frags = [&](auto slot_t, auto kk_t, auto stage_t) {
         constexpr int SLOT = decltype(slot_t)::value, KK = decltype(kk_t)::value, S = decltype(stage_t)::value;
         static_for<0, TM>([&](auto b_t) {
             constexpr int b = decltype(b_t)::value;
-            lds_read64<S * kStageBytes + Operand<LA>::template frag_imm<b, KK>()>(fa[SLOT][b], oa.template frag_reg<b, KK>());
+            lds_read<S * kStageBytes + OA::template frag_imm<b, KK>()>(fa[SLOT][b], oa.template frag_reg<b, KK>());
         });
         static_for<0, TN>([&](auto b_t) {
             constexpr int b = decltype(b_t)::value;
-            lds_read64<S * kStageBytes + Operand<LB>::template frag_imm<b, KK>()>(fb[SLOT][b], ob.template frag_reg<b, KK>());
+            lds_read<S * kStageBytes + OB::template frag_imm<b, KK>()>(fb[SLOT][b], ob.template frag_reg<b, KK>());
         });
     };
     auto frags_wait = [&](auto slot_t) {
         constexpr int SLOT = decltype(slot_t)::value;
         static_assert(TM == 4 && TN == 4, "operand list of lds_wait");
-        lds_wait(fa[SLOT][0], fa[SLOT][1], fa[SLOT][2], fa[SLOT][3], fb[SLOT][0], fb[SLOT][1], fb[SLOT][2], fb[SLOT][3]);
+        lds_wait8(fa[SLOT][0], fa[SLOT][1], fa[SLOT][2], fa[SLOT][3], fb[SLOT][0], fb[SLOT][1], fb[SLOT][2], fb[SLOT][3]);
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
@@ -237,35 +279,40 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
 
     // One K-tile out of stage S.  Every instruction that is not an MFMA is dealt out behind one, in an order
     // pinned with sched_barrier:
-    //   k-step 0: fragment reads of k-step 1; the four DMAs of K-tile +3 into stage S + 3;
-    //   wait (K-tile +1 has landed: the eight DMAs issued since may still be in flight), barrier (every
-    //   wave's part of it is there, and every wave is done reading stage S, which the next tile's DMAs overwrite);
-    //   k-step 1: first fragment reads of K-tile +1; the k offsets of the tile requested next.
+    //   every k-step: the fragment reads of the next one (of K-tile +1's first in the last);
+    //   k-step 0: the four DMAs of K-tile +3 into stage S + 3;
+    //   before the last k-step: wait (K-tile +1 has landed: the eight DMAs issued since may still be in
+    //   flight), barrier (every wave's part of it is there, and every wave is done reading stage S, which
+    //   the next tile's DMAs overwrite);
+    //   last k-step: the k offsets of the tile requested next.
     auto tile_step = [&](auto stage_t) {
         constexpr int S = decltype(stage_t)::value, SN = (S + 1) % kStages, SL = (S + kStages - 1) % kStages;
         const unsigned ld = smem_lds + SL * kStageBytes;
         frags_wait(I0());
         k_wait();  // requested a k-step ago, and the fragment wait has covered it
         const int64_t ka = ka_next, kb = kb_next;
-        static_for<0, NMFMA>([&](auto q_t) {
-            constexpr int q = decltype(q_t)::value;
-            acc[q / TN][q % TN] = Tr::mfma(fa[0][q / TN], fb[0][q % TN], acc[q / TN][q % TN]);
-            if (q == 0) read_frags(I1(), I1(), stage_t);
-            if (q >= 2 && q < 2 + 3 * NDMA && (q - 2) % 3 == 0) issue((q - 2) / 3, ld, ka, kb);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        // a bare s_barrier: __syncthreads() carries a fence, which with LDS-DMA in flight becomes a full
-        // drain of the memory counter.  What the fence would order is ordered by hand: this wave's DMAs of
-        // K-tile +1 have landed (vmcnt), its reads of stage S have returned (lgkmcnt).
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDMA) : "memory");
-        __builtin_amdgcn_s_barrier();
-        frags_wait(I1());
-        static_for<0, NMFMA>([&](auto q_t) {
-            constexpr int q = decltype(q_t)::value;
-            acc[q / TN][q % TN] = Tr::mfma(fa[1][q / TN], fb[1][q % TN], acc[q / TN][q % TN]);
-            if (q == 0) read_frags(I0(), I0(), std::integral_constant<int, SN>());
-            if (q == 1) advance();
-            __builtin_amdgcn_sched_barrier(0);
+        static_for<0, KSTEPS>([&](auto kk_t) {
+            constexpr int kk = decltype(kk_t)::value, slot = kk & 1;
+            constexpr bool last = (kk == KSTEPS - 1);
+            if (last) {
+                // a bare s_barrier: __syncthreads() carries a fence, which with LDS-DMA in flight becomes a
+                // full drain of the memory counter.  What the fence would order is ordered by hand: this
+                // wave's DMAs of K-tile +1 have landed (vmcnt), its reads of stage S have returned (lgkmcnt).
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDMA) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (kk > 0) frags_wait(std::integral_constant<int, slot>());
+            static_for<0, NMFMA>([&](auto q_t) {
+                constexpr int q = decltype(q_t)::value;
+                acc[q / TN][q % TN] = Tr::mfma(fa[slot][q / TN], fb[slot][q % TN], acc[q / TN][q % TN]);
+                if (q == 0) {
+                    if (last) read_frags(std::integral_constant<int, slot ^ 1>(), I0(), std::integral_constant<int, SN>());
+                    else read_frags(std::integral_constant<int, slot ^ 1>(), std::integral_constant<int, (kk + 1) % KSTEPS>(), stage_t);
+                }
+                if (kk == 0 && q >= 2 && q < 2 + 3 * NDMA && (q - 2) % 3 == 0) issue((q - 2) / 3, ld, ka, kb);
+                if (last && q == 1) advance();
+                __builtin_amdgcn_sched_barrier(0);
+            });
         });
     };
 
@@ -286,7 +333,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     frags_wait(I0());
 
-    store_tile<double, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, sid, chunk);
+    store_tile<T, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, sid, chunk);
 #ifdef CTC_CLOCK
     if (t == 0 && blockIdx.y == 0 && (blockIdx.x == 700 || blockIdx.x == 2500 || blockIdx.x == 4500)) {
         const unsigned long long dc = __builtin_readcyclecounter() - ck_core0, dr = __builtin_amdgcn_s_memrealtime() - ck_real0;
@@ -295,7 +342,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_f64_kernel(const GemmParams p
 #endif
 }
 
-template <int LA, int LB> int resident_slots()
+template <typename T, int LA, int LB> int resident_slots()
 {
     static std::atomic<int> cache[64];  // 0: not queried yet; host threads of several devices may race here
     int dev = 0;
@@ -303,26 +350,26 @@ template <int LA, int LB> int resident_slots()
     if (cache[dev].load() == 0) {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_f64_kernel<LA, LB>, 256, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<T, LA, LB>, 256, 0) != hipSuccess) return 0;
         cache[dev].store(cus * per_cu > 0 ? cus * per_cu : -1);
     }
     const int slots = cache[dev].load();
     return slots > 0 ? slots : 0;
 }
 
-// chunk overhead of the split along K, in K-tiles (of 8 here): prologue, raw sums to the workspace, the
-// chunk's share of the fix-up pass; the same 128 contracted elements as in gemm_kernels.hip
-constexpr int kMinChunkTiles = 16;
+// Chunk overhead of the split along K, in contracted elements: prologue, raw sums to the workspace, the
+// chunk's share of the fix-up pass; the same 128 as in gemm_kernels.hip.
+constexpr int kMinChunkK = 128;
 
-int best_split(int64_t tail, int slots, int nk)
+int best_split(int64_t tail, int slots, int nk, int min_chunk_tiles)
 {
-    int fmax = nk / kMinChunkTiles;
+    int fmax = nk / min_chunk_tiles;
     if (fmax > 1024) fmax = 1024;
     int best_f = 1;
     double best = (double)nk;
     for (int f = 2; f <= fmax; ++f) {
         const double rounds = (double)((tail * f + slots - 1) / slots);
-        const double cost = rounds * ((double)nk / f + kMinChunkTiles);
+        const double cost = rounds * ((double)nk / f + min_chunk_tiles);
         if (cost < best * 0.98) {
             best = cost;
             best_f = f;
@@ -331,8 +378,9 @@ int best_split(int64_t tail, int slots, int nk)
     return best_f;
 }
 
-template <int LA, int LB> hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
+template <typename T, int LA, int LB> hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
 {
+    constexpr int BK = tile_k<T>();
     GemmSchedule s;
     s.nbm = (int)((p.M + kBM - 1) / kBM);
     s.nbn = (int)((p.N + kBN - 1) / kBN);
@@ -343,17 +391,17 @@ template <int LA, int LB> hipError_t schedule_one(const GemmParams &p, GemmSched
     s.tail_tiles = 0;
     s.ws_bytes = 0;
     static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
-    const int slots = resident_slots<LA, LB>();
-    const int nk = (int)(p.K / kBK);
+    const int slots = resident_slots<T, LA, LB>();
+    const int nk = (int)(p.K / BK);
     if (!no_split && slots > 0 && p.batch == 1) {
         const int tail = (int)(tiles % slots);
         if (tail > 0) {
-            const int f = best_split(tail, slots, nk);
+            const int f = best_split(tail, slots, nk, kMinChunkK / BK);
             if (f >= 2) {
                 s.tail_tiles = tail;
                 s.dp_tiles = (int)tiles - tail;
                 s.split = f;
-                s.ws_bytes = (size_t)tail * f * kBM * kBN * sizeof(double);
+                s.ws_bytes = (size_t)tail * f * kBM * kBN * sizeof(T);
             }
         }
     }
@@ -361,7 +409,7 @@ template <int LA, int LB> hipError_t schedule_one(const GemmParams &p, GemmSched
     return hipSuccess;
 }
 
-template <int LA, int LB>
+template <typename T, int LA, int LB>
 hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     GemmParams q = p;
@@ -373,51 +421,57 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
     dim3 grid((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1);
-    hipLaunchKernelGGL((gemm_dma_f64_kernel<LA, LB>), grid, dim3(256), 0, stream, q);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, LA, LB>), grid, dim3(256), 0, stream, q);
     if (sch.tail_tiles > 0) {
-        hipError_t e = launch_splitk_fixup_f64(q, sch.tail_tiles, stream);
+        hipError_t e = launch_splitk_fixup_128(sizeof(T) == 8 ? 0 : 1, q, sch.tail_tiles, stream);
         if (e != hipSuccess) return e;
     }
     return hipGetLastError();
 }
 
+template <typename T>
+hipError_t dispatch(int layout_a, int layout_b, const GemmParams &p, GemmSchedule *sch_out, const GemmSchedule *sch_in,
+                    void *ws, hipStream_t stream)
+{
+#define CTC_CASE(A_, B_) \
+    case A_ * 2 + B_: return sch_out ? schedule_one<T, A_, B_>(p, sch_out) : launch_one<T, A_, B_>(p, *sch_in, ws, stream);
+    switch (layout_a * 2 + layout_b) {
+        CTC_CASE(0, 0) CTC_CASE(0, 1) CTC_CASE(1, 0) CTC_CASE(1, 1)
+    default: return hipErrorInvalidValue;
+    }
+#undef CTC_CASE
+}
+
 }  // namespace
 
-bool dma_gemm_f64_supported(int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
+bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
 {
     static const bool off = getenv("CTC_TC_NO_DMA_GEMM") != nullptr;
-    if (off || bm != kBM || bn != kBN) return false;
+    if (off || bm != kBM || bn != kBN || (dtype != 0 && dtype != 1)) return false;
     if ((layout_a != 0 && layout_a != 1) || (layout_b != 0 && layout_b != 1)) return false;
-    if (p.k8_affine == 0 || p.K < kBK || p.K % kBK != 0 || p.batch < 1 || p.batch > 65535) return false;
-    if (p.M < 2 || p.N < 2) return false;
-    if (layout_a == 1 && p.M % 2 != 0) return false;
-    if (layout_b == 1 && p.N % 2 != 0) return false;
+    const int bk = dtype == 0 ? tile_k<double>() : tile_k<float>(), vec = dtype == 0 ? 2 : 4;
+    if ((dtype == 0 ? p.k8_affine : p.k16_affine) == 0 || p.K < bk || p.K % bk != 0 || p.batch < 1 || p.batch > 65535) return false;
+    if (p.M < vec || p.N < vec) return false;
+    if (layout_a == 1 && p.M % vec != 0) return false;
+    if (layout_b == 1 && p.N % vec != 0) return false;
     if (layout_a == 0 && p.ka_in != 1) return false;
     if (layout_b == 0 && p.kb_in != 1) return false;
+    // an fp32 outer-major lane offset carries one step along k
+    if (dtype == 1 && (p.ka_in >= (int64_t(1) << 28) || p.kb_in >= (int64_t(1) << 28))) return false;
     return true;
 }
 
-hipError_t schedule_gemm_dma_f64(int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out)
+hipError_t schedule_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out)
 {
-    switch (layout_a * 2 + layout_b) {
-    case 0: return schedule_one<0, 0>(p, out);
-    case 1: return schedule_one<0, 1>(p, out);
-    case 2: return schedule_one<1, 0>(p, out);
-    case 3: return schedule_one<1, 1>(p, out);
-    default: return hipErrorInvalidValue;
-    }
+    return dtype == 0 ? dispatch<double>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr)
+                      : dispatch<float>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr);
 }
 
-hipError_t launch_gemm_dma_f64(int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
-                               void *workspace, hipStream_t stream)
+hipError_t launch_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
+                           void *workspace, hipStream_t stream)
 {
-    switch (layout_a * 2 + layout_b) {
-    case 0: return launch_one<0, 0>(p, schedule, workspace, stream);
-    case 1: return launch_one<0, 1>(p, schedule, workspace, stream);
-    case 2: return launch_one<1, 0>(p, schedule, workspace, stream);
-    case 3: return launch_one<1, 1>(p, schedule, workspace, stream);
-    default: return hipErrorInvalidValue;
-    }
+    return dtype == 0 ? dispatch<double>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream)
+                      : dispatch<float>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream);
 }
 
 }  // namespace ctc

@@ -562,16 +562,19 @@ hipError_t dispatch(int dtype, int la, int lb, int bm, int bn, const GemmParams 
 
 }  // namespace
 
-hipError_t launch_splitk_fixup_f64(const GemmParams &p, int tail_tiles, hipStream_t stream)
+hipError_t launch_splitk_fixup_128(int dtype, const GemmParams &p, int tail_tiles, hipStream_t stream)
 {
-    hipLaunchKernelGGL((splitk_fixup_kernel<double, 128, 128>), dim3((unsigned)(tail_tiles * (128 / 16))), dim3(256), 0, stream, p);
+    const dim3 grid((unsigned)(tail_tiles * (128 / 16)));
+    if (dtype == 0) hipLaunchKernelGGL((splitk_fixup_kernel<double, 128, 128>), grid, dim3(256), 0, stream, p);
+    else if (dtype == 1) hipLaunchKernelGGL((splitk_fixup_kernel<float, 128, 128>), grid, dim3(256), 0, stream, p);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
 hipError_t schedule_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p, GemmSchedule *out)
 {
     if (dtype == 2) return schedule_gemm_bf16(layout_a, layout_b, bm, p, out);
-    if (dtype == 0 && dma_gemm_f64_supported(layout_a, layout_b, bm, bn, p)) return schedule_gemm_dma_f64(layout_a, layout_b, p, out);
+    if (dma_gemm_supported(dtype, layout_a, layout_b, bm, bn, p)) return schedule_gemm_dma(dtype, layout_a, layout_b, p, out);
     return dispatch(dtype, layout_a, layout_b, bm, bn, p, out, nullptr, nullptr, nullptr);
 }
 
@@ -579,8 +582,8 @@ hipError_t launch_gemm(int dtype, int layout_a, int layout_b, int bm, int bn, co
                        const GemmSchedule &schedule, void *workspace, hipStream_t stream)
 {
     if (dtype == 2) return launch_gemm_bf16(layout_a, layout_b, bm, p, schedule, workspace, stream);
-    if (dtype == 0 && dma_gemm_f64_supported(layout_a, layout_b, bm, bn, p))
-        return launch_gemm_dma_f64(layout_a, layout_b, p, schedule, workspace, stream);
+    if (dma_gemm_supported(dtype, layout_a, layout_b, bm, bn, p))
+        return launch_gemm_dma(dtype, layout_a, layout_b, p, schedule, workspace, stream);
     return dispatch(dtype, layout_a, layout_b, bm, bn, p, nullptr, &schedule, workspace, stream);
 }
 

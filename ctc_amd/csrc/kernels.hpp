@@ -39,7 +39,8 @@ struct GemmParams {
     int64_t ka_stride = 0, kb_stride = 0;
     // k8_affine != 0: K is a multiple of 8 and inside every aligned group of 8 the k offsets are affine,
     // k_a[8 g + i] == k_a[8 g] + i * ka_in (likewise k_b, kb_in): a K-tile of 8 needs one table entry
-    int k8_affine = 0;
+    // k16_affine: the same for groups of 16
+    int k8_affine = 0, k16_affine = 0;
     int64_t ka_in = 0, kb_in = 0;
 };
 
@@ -67,14 +68,14 @@ hipError_t launch_gemm_stream(int dtype, int layout_a, int layout_b, const GemmP
 bool stream_gemm_f64_dma_supported(int layout_a, int layout_b, const GemmParams &p);
 hipError_t launch_gemm_stream_f64_dma(int layout_a, int layout_b, const GemmParams &p, hipStream_t stream);
 
-// fp64, 128 x 128 tiles, operands staged by LDS-DMA (gemm_dma_f64_kernels.hip); schedule_gemm / launch_gemm
-// route to it when dma_gemm_f64_supported says the launch qualifies (vector layouts, k8_affine).
-bool dma_gemm_f64_supported(int layout_a, int layout_b, int bm, int bn, const GemmParams &p);
-hipError_t schedule_gemm_dma_f64(int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out);
-hipError_t launch_gemm_dma_f64(int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
-                               void *workspace, hipStream_t stream);
-// the split-K fix-up pass of 128 x 128 fp64 tiles (gemm_kernels.hip); p carries the schedule
-hipError_t launch_splitk_fixup_f64(const GemmParams &p, int tail_tiles, hipStream_t stream);
+// fp64 / fp32, 128 x 128 tiles, operands staged by LDS-DMA (gemm_dma_kernels.hip); schedule_gemm / launch_gemm
+// route to it when dma_gemm_supported says the launch qualifies (vector layouts, k8_affine / k16_affine).
+bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p);
+hipError_t schedule_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out);
+hipError_t launch_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
+                           void *workspace, hipStream_t stream);
+// the split-K fix-up pass of 128 x 128 tiles, dtype 0 / 1 (gemm_kernels.hip); p carries the schedule
+hipError_t launch_splitk_fixup_128(int dtype, const GemmParams &p, int tail_tiles, hipStream_t stream);
 
 // bf16 operands and result, f32 accumulation (gemm_bf16_kernels.hip): square tiles, bm = 128 or 256
 // (256 only with 16-byte-vector layouts on both operands, otherwise 128 is used), K-tile 64;

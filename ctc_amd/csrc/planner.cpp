@@ -324,15 +324,16 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
     p.ka_stride = affine(p.k_a);
     p.kb_stride = affine(p.k_b);
     {
-        auto affine8 = [](const std::vector<int64_t> &tab, int64_t K, int64_t &step) {
-            if (K < 8 || K % 8 != 0) return false;
+        auto affine_groups = [](const std::vector<int64_t> &tab, int64_t K, int group, int64_t &step) {
+            if (K < group || K % group != 0) return false;
             step = tab[1] - tab[0];
-            for (int64_t g = 0; g < K; g += 8)
-                for (int i = 1; i < 8; ++i)
+            for (int64_t g = 0; g < K; g += group)
+                for (int i = 1; i < group; ++i)
                     if (tab[g + i] != tab[g] + i * step) return false;
             return true;
         };
-        p.k8_affine = affine8(p.k_a, p.K, p.ka_in) && affine8(p.k_b, p.K, p.kb_in);
+        p.k16_affine = affine_groups(p.k_a, p.K, 16, p.ka_in) && affine_groups(p.k_b, p.K, 16, p.kb_in);
+        p.k8_affine = affine_groups(p.k_a, p.K, 8, p.ka_in) && affine_groups(p.k_b, p.K, 8, p.kb_in);
     }
     build_table(p, p.ex_n, gb, p.N, p.col_b);
     for (int64_t v : p.row_a) p.max_row_a = v > p.max_row_a ? v : p.max_row_a;

@@ -19,9 +19,9 @@ def counters(directory, counter):
                 continue
             if "splitk_fixup" in name:
                 out["fixup"].append(float(value))
-            elif "gemm_kernel" in name or "gemm_dma_f64_kernel" in name:
+            elif "gemm_kernel" in name or "gemm_dma_kernel" in name:
                 out["gemm"].append(float(value))
-                key = "gemm_dma_f64_kernel" if "gemm_dma_f64_kernel" in name else "gemm_kernel"
+                key = "gemm_dma_kernel" if "gemm_dma_kernel" in name else "gemm_kernel"
                 out["gemm_name"] = name[name.index(key):].split("(")[0]
             elif "copyBuffer" in name:
                 out["copy"].append(float(value))
