@@ -16,3 +16,7 @@ python3 $R/tools/traffic_summary.py $R/gpurun_out/traffic_FETCH_SIZE $R/gpurun_o
 bash $R/tools/pmc_case.sh ccsd96 > $R/gpurun_out/r02b_pmc_ccsd96.txt 2>&1 || { tail -5 $R/gpurun_out/r02b_pmc_ccsd96.txt; exit 1; }
 bash $R/tools/pmc_case.sh six > $R/gpurun_out/r02b_pmc_six.txt 2>&1 || { tail -5 $R/gpurun_out/r02b_pmc_six.txt; exit 1; }
 tail -12 $R/gpurun_out/r02b_pmc_ccsd96.txt
+cd $R
+timeout -k 10 300 python tools/extent_sweep.py f64 > gpurun_out/r02b_extent_sweep_f64.jsonl 2>/dev/null
+timeout -k 10 300 python tools/extent_sweep.py f32 > gpurun_out/r02b_extent_sweep_f32.jsonl 2>/dev/null
+timeout -k 10 300 python tools/stream_cmp.py all > gpurun_out/r02b_stream_cmp.jsonl 2>/dev/null
