@@ -158,3 +158,41 @@ def test_headline_contraction_at_extent_64_properties(cuda, oracle):
         want = oracle.contract(spec, sub, np.ascontiguousarray(A[a0:a0 + 1]).reshape(-1),
                                np.ascontiguousarray(B[:, b0:b0 + 1]).reshape(-1), dtype=0).reshape(n, n)
         assert np.abs(C[a0, b0] - want).max() <= TOL["f64"] * np.abs(want).max()
+
+
+def test_seeded_random_contractions_on_large_tiles(cuda, oracle):
+    """Random mode orders, extents, element types, alpha and beta on problems large enough for the
+    128 x 128 tile (the generic random test draws small ones): whichever kernel the launch takes must
+    match the oracle, and the LDS-DMA kernel must take a fair share of them."""
+    import random
+    rng = random.Random(0xD3A)
+    took_dma = 0
+    n_cases = 30
+    for n in range(n_cases):
+        dtype = rng.choice(["f64", "f64", "f32"])
+        ext = dict(a=rng.choice([56, 60, 66]), i=rng.choice([48, 56, 64]),
+                   b=rng.choice([56, 60, 66]), j=rng.choice([48, 56, 64]),
+                   e=rng.choice([1, 2, 3, 5]), m=rng.choice([8, 16, 16, 24, 32, 40, 50]))
+        la, lb, lc = list("aeim"), list("ebmj"), list("abij")
+        for m in (la, lb, lc):
+            rng.shuffle(m)
+        if ext["e"] == 1 and rng.random() < 0.5:  # one contracted mode only
+            la.remove("e")
+            lb.remove("e")
+            del ext["e"]
+        spec = "%s,%s->%s" % ("".join(la), "".join(lb), "".join(lc))
+        alpha, beta = rng.choice([1.0, -0.5, 2.0]), rng.choice([0.0, 0.0, 1.0, -1.5])
+        size = lambda m: int(np.prod([ext[c] for c in m]))  # noqa: E731
+        A = oracle.fill(size(la), 100 + n, CODE[dtype])
+        B = oracle.fill(size(lb), 200 + n, CODE[dtype])
+        C0 = oracle.fill(size(lc), 300 + n, CODE[dtype])
+        plan = ctc_amd.Plan(spec, ext, dtype)
+        dC = torch.from_numpy(C0.copy()).to(cuda)
+        d = _delta(lambda: plan.execute(torch.from_numpy(A).to(cuda), torch.from_numpy(B).to(cuda), dC, alpha=alpha, beta=beta))
+        took_dma += d[1]
+        want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=alpha, beta=beta, dtype=CODE[dtype])
+        got = dC.cpu().numpy().astype(np.float64)
+        err = np.abs(got - want.astype(np.float64)).max()
+        scale = np.abs(want).max()
+        assert err <= TOL[dtype] * scale, (n, spec, ext, dtype, alpha, beta, plan.summary()["tile"], d, err, scale)
+    assert took_dma >= n_cases // 6, took_dma
