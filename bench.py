@@ -18,7 +18,9 @@ collective.
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -225,15 +227,75 @@ def _claim_stdout():
 
 RESULT = None  # the original stdout, claimed in main()
 
+# A child process that owns the original stdout and prints the LAST line it was offered, once, when its
+# pipe closes, i.e. when this process is done or dies.  The headline line is offered as soon as it is
+# measured, the same line with config.variants filled in after the secondary measurements: whatever a
+# secondary measurement does at a world size that was never rehearsed (a collective that hangs, an abort
+# inside a library), the run still prints exactly one line with the headline numbers.
+KEEPER_SOURCE = (
+    "import signal, sys\n"
+    "signal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+    "signal.signal(signal.SIGINT, signal.SIG_IGN)\n"
+    "last = None\n"
+    "for line in sys.stdin:\n"
+    "    if line.strip():\n"
+    "        last = line\n"
+    "if last:\n"
+    "    sys.stdout.write(last)\n"
+    "    sys.stdout.flush()\n"
+)
+KEEPER = None
+
+
+def start_keeper():
+    """Rank 0, before anything touches the GPU."""
+    global KEEPER
+    r, w = os.pipe()
+    proc = subprocess.Popen([sys.executable, "-c", KEEPER_SOURCE], stdin=r, stdout=RESULT.fileno(), close_fds=True)
+    os.close(r)
+    KEEPER = (proc, os.fdopen(w, "w"))
+
+
+def offer(obj):
+    """The line to print unless a later one replaces it."""
+    KEEPER[1].write(json.dumps(obj) + "\n")
+    KEEPER[1].flush()
+
+
+def finish():
+    """Closes the keeper's pipe (it prints the last line offered) and waits for it."""
+    global KEEPER
+    if KEEPER is not None:
+        proc, w = KEEPER
+        KEEPER = None
+        w.close()
+        proc.wait()
+
 
 def emit(obj):
-    RESULT.write(json.dumps(obj) + "\n")
-    RESULT.flush()
+    offer(obj)
+    finish()
+
+
+def watchdog(seconds, rank):
+    """Ends this rank if the secondary measurements do not return (rank 0 prints what it has first).  A
+    thread, not a signal handler: the main thread may be stuck inside a library call."""
+    def fire():
+        sys.stderr.write("bench.py: secondary measurements still running after %d s on rank %d: giving up on them\n" % (seconds, rank))
+        sys.stderr.flush()
+        finish()
+        os._exit(0)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def main():
     global RESULT
     RESULT = _claim_stdout()
+    if int(os.environ.get("RANK", "0")) == 0:
+        start_keeper()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -245,6 +307,8 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the result against the CPU oracle")
     ap.add_argument("--shard", choices=("free", "contracted"), default="free")
     ap.add_argument("--prewarm", type=float, default=0.1, help="seconds of untimed load before the warm-up steps")
+    ap.add_argument("--variant-timeout", type=float, default=240.0,
+                    help="seconds after which the secondary measurements are abandoned (the headline line is printed without them)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -321,20 +385,6 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rel_err = float(t[0])
 
-    # Secondary measurements, after and outside the headline's timed region (every rank takes part; a
-    # failure in one of them is reported in its place and does not cost the headline line).
-    variants = {}
-    if not args.no_variants:
-        del C
-        torch.cuda.empty_cache()
-        for name, fn in (("config4_free_index_strong", lambda: run_config4(world, rank, dev, backend, 4, 2)),
-                         ("contracted_index_reduce_scatter", lambda: run_contracted(n, world, rank, dev, backend, 6, 2))):
-            try:
-                variants[name] = fn()
-            except Exception as e:  # noqa: BLE001
-                variants[name] = {"error": "%s: %s" % (type(e).__name__, e)}
-            torch.cuda.empty_cache()
-
     if rank == 0:
         s = plan.summary()
         # which tiled-GEMM kernel the timed launches took (the library counts them)
@@ -361,7 +411,7 @@ def main():
                 "tile": [128, 128, 8] if s["kernel_name"].startswith("gemm_dma") else list(s["tile"]), "layout_a": s["layout_a"], "layout_b": s["layout_b"],
                 "flops_per_step": flops_job,
                 "pct_of_fp64_mfma_peak": round(100.0 * value / (PEAK_FP64_MFMA_TFLOPS * world), 2),
-                "variants": variants,
+                "variants": {},
             },
             "roofline": {
                 "bound": "mfma",
@@ -392,7 +442,28 @@ def main():
                           "oracle (OpenMP over the outermost free index, every CPU of this job's share); the "
                           "reference has no CPU contraction path" % (args.cpu_extent, args.cpu_extent, dt),
             }
-        emit(out)
+        offer(out)  # printed as it stands if the secondary measurements take the process down
+
+    # Secondary measurements, after and outside the headline's timed region (every rank takes part; a
+    # failure in one of them is reported in its place and does not cost the headline line).
+    if not args.no_variants:
+        guard = watchdog(args.variant_timeout, rank)
+        variants = {}
+        del C
+        torch.cuda.empty_cache()
+        for name, fn in (("config4_free_index_strong", lambda: run_config4(world, rank, dev, backend, 4, 2)),
+                         ("contracted_index_reduce_scatter", lambda: run_contracted(n, world, rank, dev, backend, 6, 2))):
+            try:
+                variants[name] = fn()
+            except Exception as e:  # noqa: BLE001
+                variants[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+        guard.cancel()
+        if rank == 0:
+            out["config"]["variants"] = variants
+            offer(out)
+    if rank == 0:
+        finish()
     if world > 1:
         dist.destroy_process_group()
 
