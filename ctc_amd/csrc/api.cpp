@@ -271,6 +271,7 @@ size_t worst_splitk_bytes(const ctc::Plan &p)
     g.batch = (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch);
     g.k8_affine = plan_k8_affine(p) ? 1 : 0;
     g.k16_affine = (g.k8_affine && p.k16_affine) ? 1 : 0;
+    g.k32_affine = (g.k16_affine && p.k32_affine) ? 1 : 0;
     g.ka_in = p.ka_in;
     g.kb_in = p.kb_in;
     size_t worst = 0;
@@ -344,6 +345,7 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     // one table entry per K-tile of 8 and 32-bit lane offsets: what the LDS-DMA kernel needs
     g.k8_affine = plan_k8_affine(p) ? 1 : 0;
     g.k16_affine = (g.k8_affine && p.k16_affine) ? 1 : 0;
+    g.k32_affine = (g.k16_affine && p.k32_affine) ? 1 : 0;
     g.ka_in = p.ka_in;
     g.kb_in = p.kb_in;
 
@@ -526,6 +528,7 @@ int64_t ctc_tc_get_option(const char *name)
     if (n == "stream_f64_dma") return g_stream_f64_dma.load();
     if (n == "dma_gemm") return g_dma_gemm.load();
     if (n == "launches_dma_gemm") return g_launches_dma_gemm.load();
+    if (n == "launches_bf16_ring") return ctc::bf16_ring_launches();
     if (n == "launches_classic") return g_launches_classic.load();
     if (n == "launches_stream") return g_launches_stream.load();
     if (n == "launches_stream_f64_dma") return g_launches_stream_dma.load();

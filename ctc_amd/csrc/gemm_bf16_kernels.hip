@@ -26,6 +26,7 @@
 // DMA (global_load_lds_dwordx4), the K tail and element-load operands through registers.
 #include "gemm_device.hpp"
 #include "kernels.hpp"
+#include "lds_dma.hpp"
 
 #include <atomic>
 #include <cstdlib>
@@ -252,6 +253,126 @@ template <bool OUTER, int BT> __device__ __forceinline__ bf8_t fragment(const un
     }
 }
 
+// Epilogue of a BT x BT tile held as TM x TN 16 x 16 f32 accumulators per wave (wave origin wm0, wn0).
+// smem: at least 2 BT BT bytes that no DMA is writing any more (the finished tile passes through them
+// on its way to 16-byte stores); every thread of the workgroup must call.
+template <int BT, int TM, int TN>
+__device__ __forceinline__ void store_tile_bf16(const GemmParams &p, f4_t (&acc)[TM][TN], unsigned char *smem, unsigned short *C,
+                                                int64_t m0, int64_t n0, int wm0, int wn0, int t, int lane, bool partial, int sid,
+                                                int chunk)
+{
+    constexpr int BM = BT, BN = BT;
+    // Epilogue.  Accumulator register r of lane l: row 4 (l >> 4) + r, column l & 15.
+    const float alpha = (float)p.alpha, beta = (float)p.beta;
+    const int frow = lane & 15;
+    if (partial) {
+        // raw f32 accumulators of this K chunk: tile-shaped slab [BM][BN] in the workspace
+        float *slab = static_cast<float *>(p.ws) + ((int64_t)(sid - p.dp_tiles) * p.split + chunk) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm0 + 16 * i + 4 * (lane >> 4) + r;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) slab[row * BN + wn0 + 16 * j + frow] = acc[i][j][r];
+            }
+        return;
+    }
+    if (p.c_vec >= 8 && beta == 0.f) {
+        // The tile goes through LDS (the operand stages are free now) and leaves in 16-byte vectors
+        // along the rows of C: 32 (16 for the 128 tile) neighbouring lanes write one whole tile row
+        // of 2 BT bytes, against 32-byte pieces per row when a quad stores its 4 x 4 block directly
+        // (16384 x 16384 x 256: 0.94 TB/s of C).  Image [row][BT] bf16, its 16-byte chunks XOR-ed
+        // with the row so that the quads' 8-byte writes of sixteen rows spread over the banks.
+        typedef gemm_detail::Traits<float> Tr;
+        constexpr int NTH = 2 * BT;         // threads of the workgroup
+        constexpr int CPR = BT / 8;         // 16-byte chunks per tile row
+        constexpr int VPT = BT * CPR / NTH;  // vectors per thread on the way out
+        const int out_chunk = t % CPR, out_row0 = t / CPR;
+        // this thread's C offsets, requested before the barrier
+        int64_t ro[VPT];
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int64_t m = m0 + out_row0 + v * (NTH / CPR);
+            ro[v] = m < p.M ? p.row_c[m] : INT64_MIN;
+        }
+        const int64_t nv = n0 + 8 * out_chunk;
+        const int64_t co = nv < p.N ? p.col_c[nv] : INT64_MIN;
+        __syncthreads();  // every wave has read its last fragments
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm0 + 16 * i + Tr::cvec_row(lane, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f4_t v = Tr::cvec(acc[i][j], lane, 0);  // every lane takes part in the exchange
+                const int col = wn0 + 16 * j + (frow & ~3);
+                u2_t w;
+                w[0] = (unsigned)f32_to_bf16(alpha * v[0]) | ((unsigned)f32_to_bf16(alpha * v[1]) << 16);
+                w[1] = (unsigned)f32_to_bf16(alpha * v[2]) | ((unsigned)f32_to_bf16(alpha * v[3]) << 16);
+                const int chunk = (col >> 3) ^ (row & (CPR - 1));
+                *reinterpret_cast<u2_t *>(smem + row * (2 * BT) + 16 * chunk + 2 * (col & 7)) = w;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int row = out_row0 + v * (NTH / CPR);
+            const u4_t w = *reinterpret_cast<const u4_t *>(smem + row * (2 * BT) + 16 * (out_chunk ^ (row & (CPR - 1))));
+            if (ro[v] != INT64_MIN && co != INT64_MIN) *reinterpret_cast<u4_t *>(C + ro[v] + co) = w;
+        }
+        return;
+    }
+    if (p.c_vec >= 4) {
+        // 8-byte stores: a 4 x 4 transpose inside each quad leaves lane q with four
+        // neighbouring columns of row register q
+        typedef gemm_detail::Traits<float> Tr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int64_t m = m0 + wm0 + 16 * i + Tr::cvec_row(lane, 0);
+            const int64_t ro = p.row_c[m < p.M ? m : 0];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int64_t n = n0 + wn0 + 16 * j + (frow & ~3);
+                const f4_t v = Tr::cvec(acc[i][j], lane, 0);  // every lane takes part in the exchange
+                if (m < p.M && n < p.N) {                      // N is a multiple of the vector length
+                    u2_t *dst = reinterpret_cast<u2_t *>(C + ro + p.col_c[n]);
+                    float o[4] = {alpha * v[0], alpha * v[1], alpha * v[2], alpha * v[3]};
+                    if (beta != 0.f) {
+                        const u2_t old = *dst;
+                        o[0] += beta * bf16_to_f32((unsigned short)(old[0] & 0xFFFFu));
+                        o[1] += beta * bf16_to_f32((unsigned short)(old[0] >> 16));
+                        o[2] += beta * bf16_to_f32((unsigned short)(old[1] & 0xFFFFu));
+                        o[3] += beta * bf16_to_f32((unsigned short)(old[1] >> 16));
+                    }
+                    u2_t w;
+                    w[0] = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+                    w[1] = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+                    *dst = w;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int64_t n = n0 + wn0 + 16 * j + frow;
+        const int64_t co = p.col_c[n < p.N ? n : 0];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + wm0 + 16 * i + 4 * (lane >> 4) + r;
+                if (m < p.M && n < p.N) {
+                    unsigned short *dst = C + p.row_c[m] + co;
+                    float o = alpha * acc[i][j][r];
+                    if (beta != 0.f) o += beta * bf16_to_f32(*dst);
+                    *dst = f32_to_bf16(o);
+                }
+            }
+        }
+    }
+}
+
 template <int LA, int LB, int BT>
 __global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(const GemmParams p)
 {
@@ -432,115 +553,203 @@ __global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(co
         __syncthreads();
     }
 
-    // Epilogue.  Accumulator register r of lane l: row 4 (l >> 4) + r, column l & 15.
-    const float alpha = (float)p.alpha, beta = (float)p.beta;
-    const int frow = lane & 15;
-    if (partial) {
-        // raw f32 accumulators of this K chunk: tile-shaped slab [BM][BN] in the workspace
-        float *slab = static_cast<float *>(p.ws) + ((int64_t)(sid - p.dp_tiles) * p.split + chunk) * (BM * BN);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm0 + 16 * i + 4 * (lane >> 4) + r;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) slab[row * BN + wn0 + 16 * j + frow] = acc[i][j][r];
-            }
-        return;
-    }
-    if (p.c_vec >= 8 && beta == 0.f) {
-        // The tile goes through LDS (the operand stages are free now) and leaves in 16-byte vectors
-        // along the rows of C: 32 (16 for the 128 tile) neighbouring lanes write one whole tile row
-        // of 2 BT bytes, against 32-byte pieces per row when a quad stores its 4 x 4 block directly
-        // (16384 x 16384 x 256: 0.94 TB/s of C).  Image [row][BT] bf16, its 16-byte chunks XOR-ed
-        // with the row so that the quads' 8-byte writes of sixteen rows spread over the banks.
-        typedef gemm_detail::Traits<float> Tr;
-        constexpr int NTH = 2 * BT;         // threads of the workgroup
-        constexpr int CPR = BT / 8;         // 16-byte chunks per tile row
-        constexpr int VPT = BT * CPR / NTH;  // vectors per thread on the way out
-        const int out_chunk = t % CPR, out_row0 = t / CPR;
-        // this thread's C offsets, requested before the barrier
-        int64_t ro[VPT];
-#pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const int64_t m = m0 + out_row0 + v * (NTH / CPR);
-            ro[v] = m < p.M ? p.row_c[m] : INT64_MIN;
-        }
-        const int64_t nv = n0 + 8 * out_chunk;
-        const int64_t co = nv < p.N ? p.col_c[nv] : INT64_MIN;
-        __syncthreads();  // every wave has read its last fragments
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = wm0 + 16 * i + Tr::cvec_row(lane, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const f4_t v = Tr::cvec(acc[i][j], lane, 0);  // every lane takes part in the exchange
-                const int col = wn0 + 16 * j + (frow & ~3);
-                u2_t w;
-                w[0] = (unsigned)f32_to_bf16(alpha * v[0]) | ((unsigned)f32_to_bf16(alpha * v[1]) << 16);
-                w[1] = (unsigned)f32_to_bf16(alpha * v[2]) | ((unsigned)f32_to_bf16(alpha * v[3]) << 16);
-                const int chunk = (col >> 3) ^ (row & (CPR - 1));
-                *reinterpret_cast<u2_t *>(smem + row * (2 * BT) + 16 * chunk + 2 * (col & 7)) = w;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const int row = out_row0 + v * (NTH / CPR);
-            const u4_t w = *reinterpret_cast<const u4_t *>(smem + row * (2 * BT) + 16 * (out_chunk ^ (row & (CPR - 1))));
-            if (ro[v] != INT64_MIN && co != INT64_MIN) *reinterpret_cast<u4_t *>(C + ro[v] + co) = w;
-        }
-        return;
-    }
-    if (p.c_vec >= 4) {
-        // 8-byte stores: a 4 x 4 transpose inside each quad leaves lane q with four
-        // neighbouring columns of row register q
-        typedef gemm_detail::Traits<float> Tr;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int64_t m = m0 + wm0 + 16 * i + Tr::cvec_row(lane, 0);
-            const int64_t ro = p.row_c[m < p.M ? m : 0];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int64_t n = n0 + wn0 + 16 * j + (frow & ~3);
-                const f4_t v = Tr::cvec(acc[i][j], lane, 0);  // every lane takes part in the exchange
-                if (m < p.M && n < p.N) {                      // N is a multiple of the vector length
-                    u2_t *dst = reinterpret_cast<u2_t *>(C + ro + p.col_c[n]);
-                    float o[4] = {alpha * v[0], alpha * v[1], alpha * v[2], alpha * v[3]};
-                    if (beta != 0.f) {
-                        const u2_t old = *dst;
-                        o[0] += beta * bf16_to_f32((unsigned short)(old[0] & 0xFFFFu));
-                        o[1] += beta * bf16_to_f32((unsigned short)(old[0] >> 16));
-                        o[2] += beta * bf16_to_f32((unsigned short)(old[1] & 0xFFFFu));
-                        o[3] += beta * bf16_to_f32((unsigned short)(old[1] >> 16));
-                    }
-                    u2_t w;
-                    w[0] = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-                    w[1] = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
-                    *dst = w;
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int64_t n = n0 + wn0 + 16 * j + frow;
-        const int64_t co = p.col_c[n < p.N ? n : 0];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t m = m0 + wm0 + 16 * i + 4 * (lane >> 4) + r;
-                if (m < p.M && n < p.N) {
-                    unsigned short *dst = C + p.row_c[m] + co;
-                    float o = alpha * acc[i][j][r];
-                    if (beta != 0.f) o += beta * bf16_to_f32(*dst);
-                    *dst = f32_to_bf16(o);
-                }
-            }
+    store_tile_bf16<BT, TM, TN>(p, acc, smem, C, m0, n0, wm0, wn0, t, lane, partial, sid, chunk);
+}
+
+// ---- ring kernel ---------------------------------------------------------------------------------------
+// The 256 x 256 tile for two K-major operands with the staging of gemm_dma_kernels.hip: K-tiles of 32 (64-byte
+// rows, one MFMA k-step) in a ring of four 32 KB stages, the DMAs of K-tile t + 4 issued during K-tile t,
+// K-tile t + 1 awaited with a counted s_waitcnt before the one bare barrier of the tile, fragment reads
+// (ds_read_b128, the next tile's while this tile's MFMAs run) and DMAs issued from assembly so that neither
+// the compiler's waits nor the vector ALU are involved.  The two-buffer kernel above waits for a DMA one
+// K-tile (0.9 us of MFMAs) after issuing it, which is less than the transfer takes under load.
+// Image [row][32 k], chunk c (8 k) of row r at chunk position c ^ ((r >> 2) & 3).
+constexpr int kRingBK = 32, kRingStages = 4;
+constexpr int kRingImage = 256 * kRingBK * 2;  // one operand's tile image
+constexpr int kRingStage = 2 * kRingImage;
+
+template <int OFF> __device__ __forceinline__ void lds_read128(u4_t &d, unsigned addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_read offset field");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_wait12(u4_t (&a)[8], u4_t (&b)[4])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]),
+                   "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+
+__global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams p)
+{
+    using namespace lds_dma;
+    constexpr int BT = 256, BM = BT, BN = BT, TM = 8, TN = 4, NMFMA = TM * TN, NDMA = 4, BK = kRingBK;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[kRingStages * kRingStage];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm0 = (wave / 4) * (16 * TM), wn0 = (wave % 4) * 64;
+    const int frow = lane & 15, kg = lane >> 4;
+
+    int sid, chunk = 0;
+    bool partial = false;
+    {
+        const int bid = blockIdx.x;
+        if (bid < p.dp_tiles) {
+            const int nblk = p.dp_tiles;
+            const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+            sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        } else {
+            const int rel = bid - p.dp_tiles;
+            sid = p.dp_tiles + rel / p.split;
+            chunk = rel % p.split;
+            partial = true;
         }
     }
+    const int width = p.group * p.nbn;
+    const int first_m = (sid / width) * p.group;
+    const int gsz = min(p.nbm - first_m, p.group);
+    const int tm = first_m + (sid % width) % gsz;
+    const int tn = (sid % width) / gsz;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int bz = blockIdx.y;
+
+    const char *A = reinterpret_cast<const char *>(static_cast<const unsigned short *>(p.A) + p.bat_a[bz]);
+    const char *B = reinterpret_cast<const char *>(static_cast<const unsigned short *>(p.B) + p.bat_b[bz]);
+    unsigned short *C = static_cast<unsigned short *>(p.C) + p.bat_c[bz];
+
+    const int nk_total = (int)(p.K / BK);
+    const int kt_first = partial ? (int)((int64_t)chunk * nk_total / p.split) : 0;
+    const int kt_last = partial ? (int)((int64_t)(chunk + 1) * nk_total / p.split) : nk_total;
+    const int nk = kt_last - kt_first;
+
+    // DMA: instruction j of wave w fills bytes [(2 w + j) KB, + 1 KB) of an image: 16 rows of 4 chunks
+    unsigned off_a[2], off_b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * (2 * wave + j) + (lane >> 2);
+        const int c = (lane & 3) ^ ((lane >> 4) & 3);
+        int64_t ga = m0 + row, gb = n0 + row;
+        if (ga > p.M - 1) ga = p.M - 1;  // rows past the extent repeat its last row: products never stored
+        if (gb > p.N - 1) gb = p.N - 1;
+        off_a[j] = (unsigned)(p.row_a[ga] * 2 + c * 16);
+        off_b[j] = (unsigned)(p.col_b[gb] * 2 + c * 16);
+    }
+    // fragments: lane (frow, kg) reads chunk kg of its row; one address register per pair of stages (the
+    // offset field of ds_read holds 64 KB)
+    const unsigned smem_lds = lds_addr(smem);
+    const unsigned swz = (unsigned)((kg ^ ((frow >> 2) & 3)) << 4);
+    unsigned fra[2], frb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        fra[h] = smem_lds + 2 * h * kRingStage + (wm0 + frow) * 64 + swz;
+        frb[h] = smem_lds + 2 * h * kRingStage + kRingImage + (wn0 + frow) * 64 + swz;
+    }
+
+    f4_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    // K-tiles are requested in order, four ahead; past the chunk's end the requests wrap to its first tiles
+    // (finite data nobody multiplies) so that every wave issues the same number of DMAs per tile.  Their k
+    // offsets come by scalar loads issued from assembly; asynchronous: k_wait() before the first use.
+    int tl = 0;
+    int64_t ka_next, kb_next;
+    auto k_fetch = [&]() {
+        const int64_t *pa = p.k_a + (int64_t)(kt_first + tl) * BK, *pb = p.k_b + (int64_t)(kt_first + tl) * BK;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(ka_next) : "s"(pa));
+        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(kb_next) : "s"(pb));
+    };
+    auto k_wait = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ka_next), "+s"(kb_next)); };
+    auto advance = [&]() {
+        tl = (tl + 1 == nk) ? 0 : tl + 1;
+        k_fetch();
+    };
+    auto issue = [&](int u, unsigned stage, int64_t ka, int64_t kb) {  // stage: LDS address
+        const int j = u & 1;
+        if (u < 2) dma16_split(A + ka * 2, off_a[j], stage + (2 * wave + j) * 1024);
+        else dma16_split(B + kb * 2, off_b[j], stage + kRingImage + (2 * wave + j) * 1024);
+    };
+    k_fetch();
+    k_wait();
+#pragma unroll
+    for (int s = 0; s < kRingStages; ++s) {
+#pragma unroll
+        for (int u = 0; u < NDMA; ++u) issue(u, smem_lds + s * kRingStage, ka_next, kb_next);
+        advance();
+        k_wait();
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");  // K-tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+
+    u4_t fa[2][TM], fb[2][TN];
+    auto read_frags = [&](auto slot_t, auto stage_t) {
+        constexpr int SLOT = decltype(slot_t)::value, S = decltype(stage_t)::value;
+        static_for<0, TM>([&](auto b_t) {
+            constexpr int b = decltype(b_t)::value;
+            lds_read128<(S & 1) * kRingStage + b * 1024>(fa[SLOT][b], fra[S >> 1]);
+        });
+        static_for<0, TN>([&](auto b_t) {
+            constexpr int b = decltype(b_t)::value;
+            lds_read128<(S & 1) * kRingStage + b * 1024>(fb[SLOT][b], frb[S >> 1]);
+        });
+    };
+    read_frags(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+
+    // One K-tile out of stage S (its fragments were requested during the previous tile): wait (K-tile + 1 has
+    // landed: the eight DMAs issued since may be in flight; this wave's fragment reads have returned),
+    // barrier (every wave's part of K-tile + 1 is there and nobody reads stage S any more), then 32 MFMAs
+    // with the fragment reads of K-tile + 1 and the DMAs of K-tile + 4 (into stage S) dealt out behind them.
+    auto tile_step = [&](auto stage_t) {
+        constexpr int S = decltype(stage_t)::value, SN = (S + 1) % kRingStages, slot = S & 1;
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        lds_wait12(fa[slot], fb[slot]);
+        k_wait();
+        const int64_t ka = ka_next, kb = kb_next;
+        const unsigned ld = smem_lds + S * kRingStage;
+        static_for<0, NMFMA>([&](auto q_t) {
+            constexpr int q = decltype(q_t)::value;
+            acc[q / TN][q % TN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fa[slot][q / TN]),
+                                                                         __builtin_bit_cast(bf8_t, fb[slot][q % TN]),
+                                                                         acc[q / TN][q % TN], 0, 0, 0);
+            if (q == 0) read_frags(std::integral_constant<int, slot ^ 1>(), std::integral_constant<int, SN>());
+            if (q >= 4 && q < 4 + 4 * NDMA && (q - 4) % 4 == 0) issue((q - 4) / 4, ld, ka, kb);
+            if (q == 22) advance();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    {
+        int kt = 0;
+        for (; kt + kRingStages <= nk; kt += kRingStages) {
+            tile_step(std::integral_constant<int, 0>());
+            tile_step(std::integral_constant<int, 1>());
+            tile_step(std::integral_constant<int, 2>());
+            tile_step(std::integral_constant<int, 3>());
+        }
+        if (kt < nk) tile_step(std::integral_constant<int, 0>());
+        if (kt + 1 < nk) tile_step(std::integral_constant<int, 1>());
+        if (kt + 2 < nk) tile_step(std::integral_constant<int, 2>());
+    }
+    // the requests past the end have landed before the epilogue takes the stages over, and the last
+    // fragment reads (of a tile nobody multiplies) have returned
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    lds_wait12(fa[0], fb[0]);
+    lds_wait12(fa[1], fb[1]);
+    __syncthreads();
+    store_tile_bf16<BT, TM, TN>(p, acc, smem, C, m0, n0, wm0, wn0, t, lane, partial, sid, chunk);
+}
+
+// both operands K-major, the 256 tile, K a multiple of 32 with k offsets affine (step 1) inside aligned
+// groups of 32, lane offsets that fit 32 bits
+bool ring_supported(int la, int lb, int bt, const GemmParams &p)
+{
+    static const bool off = getenv("CTC_TC_NO_BF16_RING") != nullptr;
+    return !off && bt == 256 && la == 0 && lb == 0 && p.k32_affine != 0 && p.ka_in == 1 && p.kb_in == 1 && p.K >= kRingBK &&
+           p.K % kRingBK == 0;
 }
 
 // Sums the K chunks of the split tiles in chunk order and writes C = alpha * sum + beta * C in bf16.
@@ -648,6 +857,28 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     return hipGetLastError();
 }
 
+std::atomic<int64_t> g_ring_launches{0};
+
+hipError_t launch_ring(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
+{
+    constexpr int BT = 256;
+    g_ring_launches.fetch_add(1);
+    GemmParams q = p;
+    q.nbm = sch.nbm;
+    q.nbn = sch.nbn;
+    q.dp_tiles = sch.dp_tiles;
+    q.split = sch.split;
+    q.ws = ws;
+    if (q.group < 1) q.group = 1;
+    if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
+    if (sch.nbm != (int)((p.M + BT - 1) / BT) || sch.nbn != (int)((p.N + BT - 1) / BT)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gemm_bf16_ring_kernel, dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1), dim3(2 * BT),
+                       0, stream, q);
+    if (sch.tail_tiles > 0)
+        hipLaunchKernelGGL(splitk_fixup_bf16_kernel<BT>, dim3((unsigned)(sch.tail_tiles * (BT / 16))), dim3(256), 0, stream, q);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 // Same policy as the f64/f32 kernel: tiles = q * slots + tail; the q full rounds run whole, each
@@ -699,11 +930,14 @@ hipError_t schedule_gemm_bf16(int la, int lb, int bm, const GemmParams &p, GemmS
     return hipSuccess;
 }
 
+int64_t bf16_ring_launches() { return g_ring_launches.load(); }
+
 hipError_t launch_gemm_bf16(int la, int lb, int bm, const GemmParams &p, const GemmSchedule &sch, void *ws,
                             hipStream_t stream)
 {
     if (la < 0 || la > 2 || lb < 0 || lb > 2) return hipErrorInvalidValue;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
+    if (ring_supported(la, lb, tile_edge(la, lb, bm), p)) return launch_ring(p, sch, ws, stream);
     if (tile_edge(la, lb, bm) == 256) {
         switch (la * 2 + lb) {
         case 0: return launch_one<0, 0, 256>(p, sch, ws, stream);

@@ -39,8 +39,8 @@ struct GemmParams {
     int64_t ka_stride = 0, kb_stride = 0;
     // k8_affine != 0: K is a multiple of 8 and inside every aligned group of 8 the k offsets are affine,
     // k_a[8 g + i] == k_a[8 g] + i * ka_in (likewise k_b, kb_in): a K-tile of 8 needs one table entry
-    // k16_affine: the same for groups of 16
-    int k8_affine = 0, k16_affine = 0;
+    // k16_affine, k32_affine: the same for groups of 16 / 32
+    int k8_affine = 0, k16_affine = 0, k32_affine = 0;
     int64_t ka_in = 0, kb_in = 0;
 };
 
@@ -83,6 +83,9 @@ hipError_t launch_splitk_fixup_128(int dtype, const GemmParams &p, int tail_tile
 hipError_t schedule_gemm_bf16(int layout_a, int layout_b, int bm, const GemmParams &p, GemmSchedule *out);
 hipError_t launch_gemm_bf16(int layout_a, int layout_b, int bm, const GemmParams &p, const GemmSchedule &schedule,
                             void *workspace, hipStream_t stream);
+// launches, since the library was loaded, that took the 256-tile ring kernel (two K-major operands, K a
+// multiple of 32, k32_affine) instead of the two-buffer kernel
+int64_t bf16_ring_launches();
 
 // Skinny contraction C(m,n) = sum_k A(m,k) B(k,n) for M <= 16: streams B once and C once.
 // transpose == 0: n is the fused N index, B(k,n) = B[k_b[k] + nb[n]], C(m,n) = C[row_c[m] + nc[n]]

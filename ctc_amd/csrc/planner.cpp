@@ -332,6 +332,7 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
                     if (tab[g + i] != tab[g] + i * step) return false;
             return true;
         };
+        p.k32_affine = affine_groups(p.k_a, p.K, 32, p.ka_in) && affine_groups(p.k_b, p.K, 32, p.kb_in);
         p.k16_affine = affine_groups(p.k_a, p.K, 16, p.ka_in) && affine_groups(p.k_b, p.K, 16, p.kb_in);
         p.k8_affine = affine_groups(p.k_a, p.K, 8, p.ka_in) && affine_groups(p.k_b, p.K, 8, p.kb_in);
     }

@@ -137,7 +137,8 @@ const char *ctc_tc_last_error(void);
 int ctc_tc_set_option(const char *name, int64_t value);
 /* Value of a knob above, or of a read-only counter of tiled-GEMM launches since the library was loaded:
  * "launches_classic" (register-staged), "launches_dma_gemm", "launches_stream" (persistent,
- * register-staged), "launches_stream_f64_dma".
+ * register-staged), "launches_stream_f64_dma", "launches_bf16_ring" (the bf16 256-tile ring kernel, a
+ * subset of "launches_classic").
  * Negative ctc_tc_status for an unknown name. */
 int64_t ctc_tc_get_option(const char *name);
 

@@ -245,3 +245,53 @@ def test_bf16_linearity_at_size(cuda):
     rows = dA.reshape(n, n)[100:132].double() @ dB.reshape(n, n).double()
     got = dC.reshape(n, n)[100:132].double()
     assert (got - rows).abs().max() <= TOL * rows.abs().max()
+
+
+# Two K-major operands, the 256 tile and a K that is a multiple of 32 with k offsets affine inside aligned
+# groups of 32 take the ring kernel (K-tiles of 32 in four stages, LDS-DMA issued from assembly).
+RING_CASES = [
+    ("one_k_tile", "ak,bk->ab", dict(a=264, b=648, k=32)),
+    ("three_k_tiles_ragged_edges", "ak,bk->ab", dict(a=520, b=392, k=96)),
+    ("seven_k_tiles", "ak,bk->ab", dict(a=300, b=777, k=224)),
+    ("splitk", "ak,bk->ab", dict(a=300, b=264, k=3072)),
+    ("two_contracted_modes", "aef,bef->ab", dict(a=392, b=264, e=3, f=64)),
+    ("modes_that_do_not_fuse", "aef,ebf->ab", dict(a=392, b=264, e=3, f=32)),
+    ("batched", "zak,zbk->zab", dict(z=3, a=264, b=328, k=64)),
+    ("permuted_result", "ak,bk->ba", dict(a=264, b=328, k=64)),
+]
+
+
+@pytest.mark.parametrize("name,spec,ext", RING_CASES, ids=[c[0] for c in RING_CASES])
+def test_bf16_ring_kernel(cuda, oracle, monkeypatch, name, spec, ext):
+    monkeypatch.setenv("CTC_TC_FORCE_TILE", "256")
+    na, nb, nc = _sizes(spec, ext)
+    A = oracle.fill(na, 0xC7C0A, BF16)
+    B = oracle.fill(nb, 0xC7C0B, BF16)
+    plan = ctc_amd.Plan(spec, ext, "bf16")
+    s = plan.summary()
+    assert tuple(s["tile"]) == (256, 256, 64) and (s["layout_a"], s["layout_b"]) == ("k_vec", "k_vec"), s
+    dC = torch.full((nc,), float("nan"), dtype=torch.bfloat16, device=cuda)
+    before = ctc_amd.get_option("launches_bf16_ring")
+    plan.execute(_to_dev(A, cuda), _to_dev(B, cuda), dC)
+    assert ctc_amd.get_option("launches_bf16_ring") == before + 1
+    want = oracle.contract(spec, ext, A, B, dtype=BF16)
+    _check(oracle, _to_host(dC), want)
+    # alpha and beta on top of that result (one more rounding: the fall-back epilogue)
+    C0 = _to_host(dC).copy()
+    plan.execute(_to_dev(A, cuda), _to_dev(B, cuda), dC, alpha=0.5, beta=-1.0)
+    _check(oracle, _to_host(dC), oracle.contract(spec, ext, A, B, C=C0, alpha=0.5, beta=-1.0, dtype=BF16))
+
+
+def test_bf16_ring_kernel_is_left_alone_when_it_does_not_apply(cuda, oracle, monkeypatch):
+    monkeypatch.setenv("CTC_TC_FORCE_TILE", "256")
+    for spec, ext in (("ak,bk->ab", dict(a=264, b=264, k=72)),      # K no multiple of 32
+                      ("ak,kb->ab", dict(a=264, b=264, k=64)),      # an outer-major operand
+                      ("aef,ebf->ab", dict(a=264, b=264, e=4, f=24))):  # groups of 32 straddle a mode of B
+        na, nb, nc = _sizes(spec, ext)
+        A = oracle.fill(na, 0xC7C0A, BF16)
+        B = oracle.fill(nb, 0xC7C0B, BF16)
+        dC = torch.full((nc,), float("nan"), dtype=torch.bfloat16, device=cuda)
+        before = ctc_amd.get_option("launches_bf16_ring")
+        ctc_amd.Plan(spec, ext, "bf16").execute(_to_dev(A, cuda), _to_dev(B, cuda), dC)
+        assert ctc_amd.get_option("launches_bf16_ring") == before, spec
+        _check(oracle, _to_host(dC), oracle.contract(spec, ext, A, B, dtype=BF16))
