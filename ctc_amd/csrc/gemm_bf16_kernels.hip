@@ -29,6 +29,7 @@
 #include "lds_dma.hpp"
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -591,6 +592,9 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm0 = (wave / 4) * (16 * TM), wn0 = (wave % 4) * 64;
     const int frow = lane & 15, kg = lane >> 4;
+#ifdef CTC_CLOCK  // diagnostic build: shader clock while this workgroup runs = core-clock ticks / 100 MHz ticks
+    const unsigned long long ck_core0 = __builtin_readcyclecounter(), ck_real0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     int sid, chunk = 0;
     bool partial = false;
@@ -740,6 +744,12 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
     lds_wait12(fa[0], fb[0]);
     lds_wait12(fa[1], fb[1]);
     __syncthreads();
+#ifdef CTC_CLOCK
+    if (t == 0 && blockIdx.y == 0 && (blockIdx.x == 100 || blockIdx.x == 500 || blockIdx.x == 900)) {
+        const unsigned long long dc = __builtin_readcyclecounter() - ck_core0, dr = __builtin_amdgcn_s_memrealtime() - ck_real0;
+        printf("[clock] block %d: %llu core ticks in %llu x 10 ns -> %.3f GHz (K loop only)\n", (int)blockIdx.x, dc, dr, (double)dc / (10.0 * (double)dr));
+    }
+#endif
     store_tile_bf16<BT, TM, TN>(p, acc, smem, C, m0, n0, wm0, wn0, t, lane, partial, sid, chunk);
 }
 
