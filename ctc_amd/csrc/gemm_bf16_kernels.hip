@@ -701,6 +701,14 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
             lds_read128<(S & 1) * kRingStage + b * 1024>(fb[SLOT][b], frb[S >> 1]);
         });
     };
+    // the same, one fragment at a time (R: 0 .. 7 A row blocks, 8 .. 11 B column blocks): a ds_read_b128 moves
+    // 1 KB and an MFMA lasts 16 cycles, so the twelve reads of a tile are dealt out behind its MFMAs instead of
+    // standing in front of the second one
+    auto read_one = [&](auto slot_t, auto stage_t, auto r_t) {
+        constexpr int SLOT = decltype(slot_t)::value, S = decltype(stage_t)::value, R = decltype(r_t)::value;
+        if constexpr (R < TM) lds_read128<(S & 1) * kRingStage + R * 1024>(fa[SLOT][R], fra[S >> 1]);
+        else lds_read128<(S & 1) * kRingStage + (R - TM) * 1024>(fb[SLOT][R - TM], frb[S >> 1]);
+    };
     read_frags(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
 
     // One K-tile out of stage S (its fragments were requested during the previous tile): wait (K-tile + 1 has
@@ -720,9 +728,21 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
             acc[q / TN][q % TN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fa[slot][q / TN]),
                                                                          __builtin_bit_cast(bf8_t, fb[slot][q % TN]),
                                                                          acc[q / TN][q % TN], 0, 0, 0);
+#ifdef CTC_BF16_RING_BURST_READS
             if (q == 0) read_frags(std::integral_constant<int, slot ^ 1>(), std::integral_constant<int, SN>());
-            if (q >= 4 && q < 4 + 4 * NDMA && (q - 4) % 4 == 0) issue((q - 4) / 4, ld, ka, kb);
-            if (q == 22) advance();
+#else
+#ifndef CTC_BF16_RING_READ_EVERY
+#define CTC_BF16_RING_READ_EVERY 2
+#endif
+#ifndef CTC_BF16_RING_DMA_FIRST
+#define CTC_BF16_RING_DMA_FIRST 1
+#endif
+            constexpr int EVERY = CTC_BF16_RING_READ_EVERY, DF = CTC_BF16_RING_DMA_FIRST;
+            if (q % EVERY == 0 && q / EVERY < TM + TN)
+                read_one(std::integral_constant<int, slot ^ 1>(), std::integral_constant<int, SN>(), std::integral_constant<int, (q / EVERY) % (TM + TN)>());
+#endif
+            if (q >= DF && q < DF + 4 * NDMA && (q - DF) % 4 == 0) issue((q - DF) / 4, ld, ka, kb);
+            if (q == 29) advance();
             __builtin_amdgcn_sched_barrier(0);
         });
     };
