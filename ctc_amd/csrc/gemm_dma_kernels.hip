@@ -427,13 +427,15 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
     unsigned items = (unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split);
-    // Four rounds of workgroups or more: one workgroup per slot, each walking its items, instead of one
-    // workgroup per item (extent 96, 10 rounds: +0.6 to +1.4 %; 80 and 88: +0.4 to +0.9 %; two or three
-    // rounds: nothing).  CTC_TC_DMA_PERSIST=0 / 1: never / whenever there are more items than slots.
+    // fp64, four rounds of workgroups or more: one workgroup per slot, each walking its items, instead of
+    // one workgroup per item (extent 96, 10 rounds: +1 to +3 %; 80 and 88: +0.4 to +0.9 %; two or three
+    // rounds: nothing).  Not fp32: there it loses (extent 96: 152.6 -> 141.8 TFLOP/s; the workgroups that
+    // share panels drift further apart and the L2 misses, which the fp64 kernel hides, show).
+    // CTC_TC_DMA_PERSIST=0 / 1: never / whenever there are more items than slots.
     static const int persist = getenv("CTC_TC_DMA_PERSIST") ? atoi(getenv("CTC_TC_DMA_PERSIST")) : -1;
     if (persist != 0) {
         const unsigned slots = (unsigned)resident_slots<T, LA, LB>();
-        if (slots >= 8 && slots % 8 == 0 && items > slots && (persist == 1 || items >= 4 * slots)) items = slots;
+        if (slots >= 8 && slots % 8 == 0 && items > slots && (persist == 1 || (sizeof(T) == 8 && items >= 4 * slots))) items = slots;
     }
     dim3 grid(items, (unsigned)p.batch, 1);
     hipLaunchKernelGGL((gemm_dma_kernel<T, LA, LB>), grid, dim3(256), 0, stream, q);
