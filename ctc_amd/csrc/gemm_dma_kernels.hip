@@ -21,7 +21,8 @@
 // inside every aligned group of that many (GemmParams::k8_affine / k16_affine; e.g. every contracted mode's
 // extent a multiple of it, or one contracted mode), row / column offsets below 2^28 elements.  Everything
 // else takes gemm_kernels.hip.
-// Tile order, split of the last round along K, epilogue: as there.
+// Tile order, split of the last round along K, epilogue: as there.  A launch may carry fewer workgroups
+// than items (fp64 with many rounds: one per slot); a workgroup then walks items b, b + gridDim.x, ...
 #include "gemm_device.hpp"
 #include "kernels.hpp"
 #include "lds_dma.hpp"

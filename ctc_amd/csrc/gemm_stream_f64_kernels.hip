@@ -3,9 +3,10 @@
 // scheme; this is its fp64 form), and every byte that travels global -> LDS goes by LDS-DMA
 // (global_load_lds_dwordx4), so the waves hold no staging registers, execute no LDS writes and wait for
 // a load exactly once per K-tile, a whole K-tile after it was issued:
-//   - three LDS stages of one 128 x 32 A tile and one 64 x 32 B tile (48 KB each, no padding);
-//     during K-tile g the DMA of K-tile g + 2 is in flight and that of g + 1 is awaited just before
-//     the barrier that ends g;
+//   - three LDS stages of one 128 x BK A tile and one 64 x BK B tile (no padding), in two geometries:
+//     K-tile 32 (48 KB a stage, one workgroup per CU, every layout) and K-tile 16 (24 KB, two workgroups
+//     per CU, outer-major operands: see Geom); during K-tile g the DMA of K-tile g + 2 is in flight and
+//     that of g + 1 is awaited just before the barrier that ends g;
 //   - a DMA instruction writes 1 KB of consecutive LDS (16 bytes per lane), so bank conflicts are
 //     removed by choosing WHICH 16-byte chunk a lane fetches instead of by padding:
 //       K-major operand (unit stride along K):  image [row][32 k], chunk c of row r stored at chunk
@@ -14,7 +15,7 @@
 //           line k stored at position c ^ ((k & 1) << 3): lines k and k + 1 of a fragment land in
 //           different halves of the banks;
 //   - the element offsets of an item (A rows, B columns, C rows, C columns) are copied from the plan's
-//     tables into a four-slot LDS ring by DMA as well, two items ahead.
+//     tables into an LDS ring by DMA as well, two items ahead.
 // The only ordinary vector-memory instructions left are the stores of C, so the in-order memory
 // counter never makes a wave wait for a store on the way to its operands.
 // Needs vector layouts on both operands, alpha == 1, beta == 0, batch == 1, even M and N, K a multiple of
