@@ -45,8 +45,11 @@ __global__ void __launch_bounds__(256) write_only(d2 *out, long long nvec, doubl
 }
 
 // SPM MFMAs between two stores; every wave owns a contiguous region of `out` and walks it.
-template <int SPM> __global__ void __launch_bounds__(256) fused(d2 *out, long long vec_per_wave, int iters, double a0, double b0)
+// clk: core-clock ticks and 100 MHz ticks workgroup 0 ran for (the shader clock under this load)
+template <int SPM>
+__global__ void __launch_bounds__(256) fused(d2 *out, long long vec_per_wave, int iters, double a0, double b0, unsigned long long *clk)
 {
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     d4 acc[16];
     for (int i = 0; i < 16; ++i) acc[i] = d4{0, 0, 0, 0};
     const double a = a0 + 0.001 * threadIdx.x, b = b0 - 0.003 * threadIdx.x;
@@ -68,6 +71,10 @@ template <int SPM> __global__ void __launch_bounds__(256) fused(d2 *out, long lo
     double s = 0;
     for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 1.2345e300) out[0] = d2{s, s};
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        clk[0] = __builtin_readcyclecounter() - c0;
+        clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 // Bursts: MPB MFMAs, then MPB / 8 stores back to back (the same one-store-per-8-MFMAs ratio).  With
@@ -107,6 +114,8 @@ int main()
     d2 *wout;
     CHECK(hipMalloc(&mout, 1024 * 256 * 8));
     CHECK(hipMalloc(&wout, wbytes));
+    unsigned long long *clk;
+    CHECK(hipMalloc(&clk, 16));
     hipStream_t s1, s2;
     CHECK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
     CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
@@ -136,16 +145,20 @@ int main()
     for (int blocks = 256; blocks <= 512; blocks *= 2) {
         const long long vec_per_wave = nvec / (blocks * 4LL);
         auto run = [&](auto kernel, int spm) {
-            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, wout, vec_per_wave, iters, 1.0, 2.0);
+            for (int w = 0; w < 4; ++w) hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, wout, vec_per_wave, iters, 1.0, 2.0, clk);
             CHECK(hipDeviceSynchronize());
             double t0 = now_ms();
-            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, wout, vec_per_wave, iters, 1.0, 2.0);
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, wout, vec_per_wave, iters, 1.0, 2.0, clk);
             CHECK(hipDeviceSynchronize());
             double t = now_ms() - t0;
+            unsigned long long h[2];
+            CHECK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
             const double fl = blocks * 4.0 * iters * 16 * 2048.0;
             const double by = blocks * 4.0 * iters * (16 / spm) * 1024.0;
-            printf("fused %d blocks, 1 store / %2d MFMA: %.3f ms  %.1f TFLOP/s  %.2f TB/s written\n", blocks, spm, t, fl / t * 1e-9,
-                   by / t * 1e-9);
+            // MFMA cycles a SIMD needs for its waves' MFMAs (64 each) over the core cycles the workgroup took
+            const double duty = (blocks / 256) * (double)iters * 16 * 64 / (double)h[0];
+            printf("fused %d blocks, 1 store / %2d MFMA: %.3f ms  %.1f TFLOP/s  %.2f TB/s written | shader clock %.2f GHz, MFMA cycles / core cycles %.3f\n",
+                   blocks, spm, t, fl / t * 1e-9, by / t * 1e-9, (double)h[0] / (10.0 * (double)h[1]), duty);
         };
         run(fused<16>, 16);
         run(fused<8>, 8);
