@@ -40,9 +40,12 @@ using namespace gemm_detail;
 using namespace lds_dma;
 
 constexpr int kBM = 128, kBN = 128, kStages = 4;
-template <typename T> constexpr int tile_k() { return 64 / (int)sizeof(T); }
-constexpr int kOpBytes = 128 * 64;         // one operand's tile image
-constexpr int kStageBytes = 2 * kOpBytes;  // A image, then B image
+// RB: bytes of k per row of a K-tile.  64 (8 fp64 / 16 fp32 contracted elements) is the geometry described
+// above; fp32 also has 32 (8 elements, two k-steps, 8 KB stages, one DMA instruction per wave and operand)
+// for contractions whose k tables are affine in groups of 8 but not of 16.
+template <typename T, int RB> constexpr int tile_k() { return RB / (int)sizeof(T); }
+template <int RB> constexpr int op_bytes() { return 128 * RB; }         // one operand's tile image
+template <int RB> constexpr int stage_bytes() { return 2 * op_bytes<RB>(); }  // A image, then B image
 
 template <int OFF> __device__ __forceinline__ void lds_read(double &d, unsigned addr) { lds_read64<OFF>(d, addr); }
 template <int OFF> __device__ __forceinline__ void lds_read(float &d, unsigned addr)
@@ -55,38 +58,45 @@ template <typename T> __device__ __forceinline__ void lds_wait8(T &a0, T &a1, T 
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
 }
 
-// What a lane fetches for its two DMA instructions per K-tile of one operand, and where a lane's MFMA
+// What a lane fetches for its NI DMA instructions per K-tile of one operand, and where a lane's MFMA
 // fragments sit in the operand's image.
-template <typename T, int LAY> struct Operand {
+template <typename T, int LAY, int RB> struct Operand {
     static constexpr bool KMAJ = (LAY != kLayOuterVec);
     static constexpr int ES = (int)sizeof(T), V = 16 / ES;  // element size, elements per 16-byte chunk
+    static constexpr int BK = RB / ES, KSTEPS = BK / 4;
+    static constexpr int NI = op_bytes<RB>() / 1024 / 4;    // DMA instructions per wave and K-tile
+    static constexpr int CPR = RB / 16;                     // K-major: chunks per row
+    static constexpr int RPI = 1024 / RB;                   // K-major: rows per instruction
     static constexpr int NFRAG = (ES == 8) ? 2 : 4;
-    unsigned off[2];       // byte offset of the lane's 16 bytes from the wave-uniform base, instructions 0 and 1
+    static_assert(ES == 4 || RB == 64, "fp64 has the 64-byte geometry only");
+    unsigned off[NI];      // byte offset of the lane's 16 bytes from the wave-uniform base, per instruction
     unsigned frag[NFRAG];  // LDS byte addresses (stage 0): K-major: of k-step kk, row block 0; outer-major: of
                            // row block b (fp64: b & 1 suffices), k-step 0
 
     // tab: the operand's row (column) offsets, r0: first row of the tile, R: the operand's extent, kin: its
-    // step along k inside a K-tile; instruction j of wave `wave` fills bytes [(2 wave + j) KB, + 1 KB) of the image
+    // step along k inside a K-tile; instruction j of wave `wave` fills bytes [(NI wave + j) KB, + 1 KB) of the image
     __device__ __forceinline__ void init_dma(const int64_t *__restrict__ tab, int64_t r0, int64_t R, int64_t kin, int lane, int wave)
     {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NI; ++j) {
+            const int inst = NI * wave + j;
             if (KMAJ) {
-                // 16 rows per instruction, 4 chunks per row
-                const int row = 16 * (2 * wave + j) + (lane >> 2);
-                const int c = (lane & 3) ^ ((lane >> 4) & 3);
+                // RPI rows per instruction, CPR chunks per row; chunk c of row r sits at position
+                // c ^ ((r / rows per 256 bytes) & (CPR - 1))
+                const int row = RPI * inst + lane / CPR;
+                const int c = (lane % CPR) ^ ((lane >> 4) & (CPR - 1));
                 int64_t g = r0 + row;
                 if (g > R - 1) g = R - 1;  // rows past the extent repeat its last row: products never stored
                 off[j] = (unsigned)(tab[g] * ES + c * 16);
             } else if (ES == 8) {
-                // one line per instruction (k = 2 wave + j, parity j), 64 chunks of two rows
-                const int c = lane ^ (j << 3);
+                // one line per instruction (k = inst), 64 chunks of two rows
+                const int c = lane ^ ((inst & 1) << 3);
                 int64_t g = r0 + 2 * c;
                 if (g > R - 2) g = R - 2;  // R is even: a pair never straddles the end
                 off[j] = (unsigned)(tab[g] * 8);
             } else {
-                // two lines per instruction (k = 4 wave + 2 j + (lane >> 5)), 32 chunks of four rows each
-                const int kq = 2 * j + (lane >> 5);  // k & 3
+                // two lines per instruction (k = 2 inst + (lane >> 5)), 32 chunks of four rows each
+                const int kq = (2 * inst + (lane >> 5)) & 3;  // k & 3
                 const int c = (lane & 31) ^ (kq << 2);
                 int64_t g = r0 + 4 * c;
                 if (g > R - 4) g = R - 4;  // R is a multiple of 4
@@ -105,10 +115,10 @@ template <typename T, int LAY> struct Operand {
             frag[1] = base ^ 32;
         } else if (KMAJ) {
             // chunk kk of the row holds k = 4 kk .. 4 kk + 3
-            const int r2 = (frow >> 2) & 3;
-            const unsigned base = image + (w0 + frow) * 64 + r2 * 16 + fk * 4;
+            const int sw = (frow / (256 / RB)) & (CPR - 1);
+            const unsigned base = image + (w0 + frow) * RB + sw * 16 + fk * 4;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) frag[kk] = base ^ (kk << 4);
+            for (int kk = 0; kk < KSTEPS; ++kk) frag[kk] = base ^ (kk << 4);
         } else if (ES == 8) {
             const int p = fk & 1;
             const unsigned base = image + fk * 1024 + ((w0 + frow) >> 1) * 16 + (frow & 1) * 8;
@@ -126,24 +136,27 @@ template <typename T, int LAY> struct Operand {
     }
     template <int b, int kk> static constexpr int frag_imm()
     {
-        return KMAJ ? b * 1024 : (ES == 8 ? 128 * b + kk * 4096 : kk * 2048);
+        return KMAJ ? b * 16 * RB : (ES == 8 ? 128 * b + kk * 4096 : kk * 2048);
     }
     // wave-uniform byte offset of instruction j of the K-tile whose first k offset (elements) is kofs
     __device__ __forceinline__ static int64_t uniform(int64_t kofs, int64_t kin, int wave, int j)
     {
-        return KMAJ ? kofs * ES : (kofs + (int64_t)((2 * wave + j) * (ES == 8 ? 1 : 2)) * kin) * ES;
+        return KMAJ ? kofs * ES : (kofs + (int64_t)((NI * wave + j) * (ES == 8 ? 1 : 2)) * kin) * ES;
     }
 };
 
-template <typename T, int LA, int LB>
+template <typename T, int LA, int LB, int RB>
 __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
 {
-    constexpr int BM = kBM, BN = kBN, BK = tile_k<T>(), WN = 2;
+    constexpr int BM = kBM, BN = kBN, BK = tile_k<T, RB>(), WN = 2;
+    constexpr int kOpBytes = op_bytes<RB>(), kStageBytes = stage_bytes<RB>();
     constexpr int TM = 4, TN = 4, NMFMA = TM * TN, KSTEPS = BK / 4;
     static_assert(KSTEPS >= 2 && KSTEPS % 2 == 0, "fragment slots alternate per k-step");
     typedef Traits<T> Tr;
     typedef typename Tr::acc_t acc_t;
-    constexpr int NDMA = 4;  // per wave per K-tile
+    typedef Operand<T, LA, RB> OA;
+    typedef Operand<T, LB, RB> OB;
+    constexpr int NI = OA::NI, NDMA = 2 * NI;  // DMA instructions per wave per K-tile
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes];
     __shared__ int64_t s_coff[BM + BN];
@@ -209,8 +222,6 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
             s_coff[idx] = ok ? off : kNoOffset;
         }
     }
-    typedef Operand<T, LA> OA;
-    typedef Operand<T, LB> OB;
     OA oa;
     OB ob;
     oa.init_dma(p.row_a, m0, p.M, p.ka_in, lane, wave);
@@ -243,11 +254,11 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     };
     k_fetch();
     k_wait();
-    // instruction u (0, 1: A; 2, 3: B) of the requested tile into stage `stage`
+    // instruction u (the first NI: A, then B) of the requested tile into stage `stage`
     auto issue = [&](int u, unsigned stage, int64_t ka, int64_t kb) {  // stage: LDS address
-        const int j = u & 1;
-        if (u < 2) dma16_split(A + OA::uniform(ka, p.ka_in, wave, j), oa.off[j], stage + (2 * wave + j) * 1024);
-        else dma16_split(B + OB::uniform(kb, p.kb_in, wave, j), ob.off[j], stage + kOpBytes + (2 * wave + j) * 1024);
+        const int j = u % NI;
+        if (u < NI) dma16_split(A + OA::uniform(ka, p.ka_in, wave, j), oa.off[j], stage + (NI * wave + j) * 1024);
+        else dma16_split(B + OB::uniform(kb, p.kb_in, wave, j), ob.off[j], stage + kOpBytes + (NI * wave + j) * 1024);
     };
     __syncthreads();  // s_coff is written; no DMA is in flight yet
 #pragma unroll
@@ -349,7 +360,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
 #endif
 }
 
-template <typename T, int LA, int LB> int resident_slots()
+template <typename T, int LA, int LB, int RB> int resident_slots()
 {
     static std::atomic<int> cache[64];  // 0: not queried yet; host threads of several devices may race here
     int dev = 0;
@@ -357,7 +368,7 @@ template <typename T, int LA, int LB> int resident_slots()
     if (cache[dev].load() == 0) {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<T, LA, LB>, 256, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<T, LA, LB, RB>, 256, 0) != hipSuccess) return 0;
         cache[dev].store(cus * per_cu > 0 ? cus * per_cu : -1);
     }
     const int slots = cache[dev].load();
@@ -385,9 +396,9 @@ int best_split(int64_t tail, int slots, int nk, int min_chunk_tiles)
     return best_f;
 }
 
-template <typename T, int LA, int LB> hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
+template <typename T, int LA, int LB, int RB> hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
 {
-    constexpr int BK = tile_k<T>();
+    constexpr int BK = tile_k<T, RB>();
     GemmSchedule s;
     s.nbm = (int)((p.M + kBM - 1) / kBM);
     s.nbn = (int)((p.N + kBN - 1) / kBN);
@@ -398,7 +409,7 @@ template <typename T, int LA, int LB> hipError_t schedule_one(const GemmParams &
     s.tail_tiles = 0;
     s.ws_bytes = 0;
     static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
-    const int slots = resident_slots<T, LA, LB>();
+    const int slots = resident_slots<T, LA, LB, RB>();
     const int nk = (int)(p.K / BK);
     if (!no_split && slots > 0 && p.batch == 1) {
         const int tail = (int)(tiles % slots);
@@ -416,7 +427,7 @@ template <typename T, int LA, int LB> hipError_t schedule_one(const GemmParams &
     return hipSuccess;
 }
 
-template <typename T, int LA, int LB>
+template <typename T, int LA, int LB, int RB>
 hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     GemmParams q = p;
@@ -435,11 +446,11 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     // CTC_TC_DMA_PERSIST=0 / 1: never / whenever there are more items than slots.
     static const int persist = getenv("CTC_TC_DMA_PERSIST") ? atoi(getenv("CTC_TC_DMA_PERSIST")) : -1;
     if (persist != 0) {
-        const unsigned slots = (unsigned)resident_slots<T, LA, LB>();
+        const unsigned slots = (unsigned)resident_slots<T, LA, LB, RB>();
         if (slots >= 8 && slots % 8 == 0 && items > slots && (persist == 1 || (sizeof(T) == 8 && items >= 4 * slots))) items = slots;
     }
     dim3 grid(items, (unsigned)p.batch, 1);
-    hipLaunchKernelGGL((gemm_dma_kernel<T, LA, LB>), grid, dim3(256), 0, stream, q);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, LA, LB, RB>), grid, dim3(256), 0, stream, q);
     if (sch.tail_tiles > 0) {
         hipError_t e = launch_splitk_fixup_128(sizeof(T) == 8 ? 0 : 1, q, sch.tail_tiles, stream);
         if (e != hipSuccess) return e;
@@ -447,12 +458,12 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     return hipGetLastError();
 }
 
-template <typename T>
+template <typename T, int RB>
 hipError_t dispatch(int layout_a, int layout_b, const GemmParams &p, GemmSchedule *sch_out, const GemmSchedule *sch_in,
                     void *ws, hipStream_t stream)
 {
 #define CTC_CASE(A_, B_) \
-    case A_ * 2 + B_: return sch_out ? schedule_one<T, A_, B_>(p, sch_out) : launch_one<T, A_, B_>(p, *sch_in, ws, stream);
+    case A_ * 2 + B_: return sch_out ? schedule_one<T, A_, B_, RB>(p, sch_out) : launch_one<T, A_, B_, RB>(p, *sch_in, ws, stream);
     switch (layout_a * 2 + layout_b) {
         CTC_CASE(0, 0) CTC_CASE(0, 1) CTC_CASE(1, 0) CTC_CASE(1, 1)
     default: return hipErrorInvalidValue;
@@ -462,34 +473,52 @@ hipError_t dispatch(int layout_a, int layout_b, const GemmParams &p, GemmSchedul
 
 }  // namespace
 
-bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
+// bytes of k per row of the K-tile the launch takes (64 or, fp32 only, 32), 0: the launch does not qualify
+int dma_gemm_row_bytes(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
 {
     static const bool off = getenv("CTC_TC_NO_DMA_GEMM") != nullptr;
-    if (off || bm != kBM || bn != kBN || (dtype != 0 && dtype != 1)) return false;
-    if ((layout_a != 0 && layout_a != 1) || (layout_b != 0 && layout_b != 1)) return false;
-    const int bk = dtype == 0 ? tile_k<double>() : tile_k<float>(), vec = dtype == 0 ? 2 : 4;
-    if ((dtype == 0 ? p.k8_affine : p.k16_affine) == 0 || p.K < bk || p.K % bk != 0 || p.batch < 1 || p.batch > 65535) return false;
-    if (p.M < vec || p.N < vec) return false;
-    if (layout_a == 1 && p.M % vec != 0) return false;
-    if (layout_b == 1 && p.N % vec != 0) return false;
-    if (layout_a == 0 && p.ka_in != 1) return false;
-    if (layout_b == 0 && p.kb_in != 1) return false;
+    if (off || bm != kBM || bn != kBN || (dtype != 0 && dtype != 1)) return 0;
+    if ((layout_a != 0 && layout_a != 1) || (layout_b != 0 && layout_b != 1)) return 0;
+    const int vec = dtype == 0 ? 2 : 4;
+    if (p.batch < 1 || p.batch > 65535 || p.M < vec || p.N < vec) return 0;
+    if (layout_a == 1 && p.M % vec != 0) return 0;
+    if (layout_b == 1 && p.N % vec != 0) return 0;
+    if (layout_a == 0 && p.ka_in != 1) return 0;
+    if (layout_b == 0 && p.kb_in != 1) return 0;
     // an fp32 outer-major lane offset carries one step along k
-    if (dtype == 1 && (p.ka_in >= (int64_t(1) << 28) || p.kb_in >= (int64_t(1) << 28))) return false;
-    return true;
+    if (dtype == 1 && (p.ka_in >= (int64_t(1) << 28) || p.kb_in >= (int64_t(1) << 28))) return 0;
+    if (dtype == 0) return (p.k8_affine && p.K >= 8 && p.K % 8 == 0) ? 64 : 0;
+    if (p.k16_affine && p.K >= 16 && p.K % 16 == 0) return 64;
+    // The 32-byte geometry has a barrier per sixteen MFMAs of 32 cycles per wave: it beats the register-staged
+    // kernel on problems of two rounds of tiles and more (headline contraction in fp32, extent 72: 127 -> 141
+    // TFLOP/s, 88: 130 -> 145) and loses below (extent 56, 625 tiles, mostly cut along K: 118 -> 110).
+    const int64_t tiles = ((p.M + kBM - 1) / kBM) * ((p.N + kBN - 1) / kBN);
+    return (p.k8_affine && p.K >= 8 && p.K % 8 == 0 && tiles * p.batch >= 1024) ? 32 : 0;
 }
 
+bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
+{
+    return dma_gemm_row_bytes(dtype, layout_a, layout_b, bm, bn, p) != 0;
+}
+
+// bm / bn are the 128 x 128 tile here: the callers have asked dma_gemm_supported
 hipError_t schedule_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out)
 {
-    return dtype == 0 ? dispatch<double>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr)
-                      : dispatch<float>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr);
+    const int rb = dma_gemm_row_bytes(dtype, layout_a, layout_b, kBM, kBN, p);
+    if (rb == 0) return hipErrorInvalidValue;
+    if (dtype == 0) return dispatch<double, 64>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr);
+    return rb == 64 ? dispatch<float, 64>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr)
+                    : dispatch<float, 32>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr);
 }
 
 hipError_t launch_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
                            void *workspace, hipStream_t stream)
 {
-    return dtype == 0 ? dispatch<double>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream)
-                      : dispatch<float>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream);
+    const int rb = dma_gemm_row_bytes(dtype, layout_a, layout_b, kBM, kBN, p);
+    if (rb == 0) return hipErrorInvalidValue;
+    if (dtype == 0) return dispatch<double, 64>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream);
+    return rb == 64 ? dispatch<float, 64>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream)
+                    : dispatch<float, 32>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream);
 }
 
 }  // namespace ctc

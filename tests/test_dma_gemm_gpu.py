@@ -60,8 +60,15 @@ CASES = [
 ]
 
 
-# fp32: K-tiles of 16; a K of 8, 24, 40, 56 or 72 is no multiple of that and stays on the other kernel
+# fp32: K-tiles of 16, or of 8 when K (or the k tables' affine groups) is a multiple of 8 only
 F32_CASES = [
+    ("k8_nn_kmajor_outer", "ak,kb->ab", dict(a=4100, b=4200, k=72)),
+    ("k8_nt_kmajor_kmajor", "ak,bk->ab", dict(a=4164, b=4032, k=40)),
+    ("k8_tn_outer_outer", "ka,kb->ab", dict(a=4200, b=4100, k=56)),
+    ("k8_tt_outer_kmajor", "ka,bk->ab", dict(a=4036, b=4292, k=24)),
+    ("k8_one_k_tile", "ak,kb->ab", dict(a=4100, b=4200, k=8)),
+    ("k8_ccsd_three_by_24", "aeim,ebmj->abij", dict(a=82, b=84, i=50, j=52, e=3, m=24)),
+    ("k8_split_k_tail", "ka,bk->ab", dict(a=4224, b=4480, k=1032)),
     ("nn_kmajor_outer", "ak,kb->ab", dict(a=2500, b=2600, k=64)),
     ("nt_kmajor_kmajor", "ak,bk->ab", dict(a=2564, b=2432, k=48)),
     ("tn_outer_outer", "ka,kb->ab", dict(a=2600, b=2500, k=80)),
@@ -121,7 +128,8 @@ def test_which_launches_take_the_dma_kernel(cuda):
     f32 = torch.zeros(4096 * 256, dtype=torch.float32, device=cuda)
     c32 = torch.zeros(4096 * 4096, dtype=torch.float32, device=cuda)
     assert _delta(lambda: ctc_amd.Plan("ak,kb->ab", dict(big, k=256), "f32").execute(f32, f32, c32)) == (0, 1, 0, 0)
-    assert _delta(lambda: ctc_amd.Plan("ak,kb->ab", dict(big, k=248), "f32").execute(f32, f32, c32)) == (1, 0, 0, 0)  # fp32: K-tiles of 16
+    assert _delta(lambda: ctc_amd.Plan("ak,kb->ab", dict(big, k=248), "f32").execute(f32, f32, c32)) == (0, 1, 0, 0)  # K-tiles of 8
+    assert _delta(lambda: ctc_amd.Plan("ak,kb->ab", dict(big, k=252), "f32").execute(f32, f32, c32)) == (1, 0, 0, 0)
     ctc_amd.set_option("dma_gemm", 0)
     try:
         assert _delta(run("ak,kb->ab", dict(big, k=256))) == (1, 0, 0, 0)
