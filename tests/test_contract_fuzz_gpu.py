@@ -1,7 +1,7 @@
 """Seeded random contractions (random mode sets, mode orders, extents, element types, alpha / beta)
 through the C ABI against the CPU oracle.  The generator favours the shapes that select different
 kernels: vector and element layouts, role swaps, batch modes, K shorter and longer than a tile,
-skinny M, split-K sized K.  CTC_FUZZ_CASES raises the number of cases (default 120)."""
+skinny M, split-K sized K.  CTC_FUZZ_CASES raises the number of cases (default 400)."""
 import os
 import random
 
@@ -57,7 +57,7 @@ def _case(rng):
 
 def _cases():
     rng = random.Random(0xC7C)
-    want = int(os.environ.get("CTC_FUZZ_CASES", "120"))
+    want = int(os.environ.get("CTC_FUZZ_CASES", "400"))
     out = []
     while len(out) < want:
         c = _case(rng)
@@ -111,7 +111,7 @@ def test_random_permutations_are_bit_exact(cuda):
     """Seeded random mode permutations (rank 1..6, element sizes 2 / 4 / 8) against numpy.transpose."""
     rng = random.Random(0x9E37)
     done = 0
-    want_cases = int(os.environ.get("CTC_FUZZ_CASES", "120"))
+    want_cases = int(os.environ.get("CTC_FUZZ_CASES", "400"))
     while done < want_cases:
         rank = rng.choice([1, 2, 2, 3, 3, 4, 4, 5, 6])
         menu = rng.choice([[1, 2, 3, 5], [4, 8, 16], [7, 33, 64], [2, 100], [16, 20, 128]])
@@ -135,7 +135,7 @@ def test_random_shardings_against_oracle(cuda, oracle):
     place; contracted: partial results summed; batch: disjoint slabs), every slab executed through its
     own sub-plan with the full tensors' strides, against the oracle's unsharded result."""
     rng = random.Random(0x5AAD)
-    want_cases = max(20, int(os.environ.get("CTC_FUZZ_CASES", "120")) // 3)
+    want_cases = max(20, int(os.environ.get("CTC_FUZZ_CASES", "400")) // 3)
     done = 0
     kinds = set()
     while done < want_cases:
@@ -198,7 +198,7 @@ def _padded(modes, ext, rng):
 def test_random_strided_operands_against_oracle(cuda, oracle):
     """Padded (non-packed) strides on A, B and C and base pointers shifted off the 16-byte grid."""
     rng = random.Random(0x57D1DE)
-    want_cases = max(20, int(os.environ.get("CTC_FUZZ_CASES", "120")) // 3)
+    want_cases = max(20, int(os.environ.get("CTC_FUZZ_CASES", "400")) // 3)
     done = 0
     while done < want_cases:
         c = _case(rng)
