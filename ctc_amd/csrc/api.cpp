@@ -255,10 +255,11 @@ std::atomic<int64_t> g_launches_classic{0}, g_launches_stream{0}, g_launches_str
 std::atomic<int> g_stream_f64_dma{1};  // 0: fp64 takes the register-staged persistent kernel too (A/B runs)
 std::atomic<int> g_dma_gemm{1};        // 0: tiled GEMMs never take the LDS-DMA kernel (A/B runs)
 std::atomic<int64_t> g_launches_dma_gemm{0};
-bool plan_k8_affine(const ctc::Plan &p)
+bool plan_dma_ok(const ctc::Plan &p)
 {
-    return g_dma_gemm.load() != 0 && p.k8_affine && p.max_row_a < (int64_t(1) << 28) && p.max_col_b < (int64_t(1) << 28);
+    return g_dma_gemm.load() != 0 && p.max_row_a < (int64_t(1) << 28) && p.max_col_b < (int64_t(1) << 28);
 }
+bool plan_k8_affine(const ctc::Plan &p) { return plan_dma_ok(p) && p.k8_affine; }
 std::atomic<int64_t> g_stream_max_k{getenv("CTC_TC_STREAM_MAX_K") ? atoll(getenv("CTC_TC_STREAM_MAX_K")) : kStreamMaxK};
 
 // The split-K workspace a tiled-GEMM plan can ask for on the current device: the largest over the
@@ -270,6 +271,7 @@ size_t worst_splitk_bytes(const ctc::Plan &p)
     g.M = p.M; g.N = p.N; g.K = p.K;
     g.batch = (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch);
     g.k8_affine = plan_k8_affine(p) ? 1 : 0;
+    g.k4_affine = (plan_dma_ok(p) && p.k4_affine) ? 1 : 0;
     g.k16_affine = (g.k8_affine && p.k16_affine) ? 1 : 0;
     g.k32_affine = (g.k16_affine && p.k32_affine) ? 1 : 0;
     g.ka_in = p.ka_in;
@@ -344,6 +346,7 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
 
     // one table entry per K-tile of 8 and 32-bit lane offsets: what the LDS-DMA kernel needs
     g.k8_affine = plan_k8_affine(p) ? 1 : 0;
+    g.k4_affine = (plan_dma_ok(p) && p.k4_affine) ? 1 : 0;
     g.k16_affine = (g.k8_affine && p.k16_affine) ? 1 : 0;
     g.k32_affine = (g.k16_affine && p.k32_affine) ? 1 : 0;
     g.ka_in = p.ka_in;

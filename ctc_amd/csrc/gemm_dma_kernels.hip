@@ -41,8 +41,8 @@ using namespace lds_dma;
 
 constexpr int kBM = 128, kBN = 128, kStages = 4;
 // RB: bytes of k per row of a K-tile.  64 (8 fp64 / 16 fp32 contracted elements) is the geometry described
-// above; fp32 also has 32 (8 elements, two k-steps, 8 KB stages, one DMA instruction per wave and operand)
-// for contractions whose k tables are affine in groups of 8 but not of 16.
+// above; 32 (4 fp64 / 8 fp32 elements: one / two k-steps, 8 KB stages, one DMA instruction per wave and
+// operand) is for contractions whose k tables are affine in groups of that many only.
 template <typename T, int RB> constexpr int tile_k() { return RB / (int)sizeof(T); }
 template <int RB> constexpr int op_bytes() { return 128 * RB; }         // one operand's tile image
 template <int RB> constexpr int stage_bytes() { return 2 * op_bytes<RB>(); }  // A image, then B image
@@ -68,7 +68,6 @@ template <typename T, int LAY, int RB> struct Operand {
     static constexpr int CPR = RB / 16;                     // K-major: chunks per row
     static constexpr int RPI = 1024 / RB;                   // K-major: rows per instruction
     static constexpr int NFRAG = (ES == 8) ? 2 : 4;
-    static_assert(ES == 4 || RB == 64, "fp64 has the 64-byte geometry only");
     unsigned off[NI];      // byte offset of the lane's 16 bytes from the wave-uniform base, per instruction
     unsigned frag[NFRAG];  // LDS byte addresses (stage 0): K-major: of k-step kk, row block 0; outer-major: of
                            // row block b (fp64: b & 1 suffices), k-step 0
@@ -107,12 +106,17 @@ template <typename T, int LAY, int RB> struct Operand {
     // w0: first row of the wave's part of the tile; image: LDS address of the operand's image in stage 0
     __device__ __forceinline__ void init_frag(unsigned image, int frow, int fk, int w0)
     {
-        if (KMAJ && ES == 8) {
+        if (KMAJ && ES == 8 && RB == 64) {
             const int r2 = (frow >> 2) & 3;
             const int phys0 = ((fk >> 1) ^ (r2 & 1)) | ((r2 >> 1) << 1);
             const unsigned base = image + (w0 + frow) * 64 + phys0 * 16 + (fk & 1) * 8;
             frag[0] = base;
             frag[1] = base ^ 32;
+        } else if (KMAJ && ES == 8) {
+            // 32-byte rows: chunk fk >> 1 of the row, at position (fk >> 1) ^ ((row >> 3) & 1); one k-step
+            const int sw = (frow >> 3) & 1;
+            frag[0] = image + (w0 + frow) * 32 + (((fk >> 1) ^ sw) << 4) + (fk & 1) * 8;
+            frag[1] = frag[0];
         } else if (KMAJ) {
             // chunk kk of the row holds k = 4 kk .. 4 kk + 3
             const int sw = (frow / (256 / RB)) & (CPR - 1);
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     constexpr int BM = kBM, BN = kBN, BK = tile_k<T, RB>(), WN = 2;
     constexpr int kOpBytes = op_bytes<RB>(), kStageBytes = stage_bytes<RB>();
     constexpr int TM = 4, TN = 4, NMFMA = TM * TN, KSTEPS = BK / 4;
-    static_assert(KSTEPS >= 2 && KSTEPS % 2 == 0, "fragment slots alternate per k-step");
+    static_assert(KSTEPS == 1 || KSTEPS % 2 == 0, "fragment slots alternate per k-step (per K-tile when it has one k-step)");
     typedef Traits<T> Tr;
     typedef typename Tr::acc_t acc_t;
     typedef Operand<T, LA, RB> OA;
@@ -304,20 +308,26 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     auto tile_step = [&](auto stage_t) {
         constexpr int S = decltype(stage_t)::value, SN = (S + 1) % kStages, SL = (S + kStages - 1) % kStages;
         const unsigned ld = smem_lds + SL * kStageBytes;
-        frags_wait(I0());
-        k_wait();  // requested a k-step ago, and the fragment wait has covered it
-        const int64_t ka = ka_next, kb = kb_next;
+        int64_t ka = 0, kb = 0;
         static_for<0, KSTEPS>([&](auto kk_t) {
-            constexpr int kk = decltype(kk_t)::value, slot = kk & 1;
+            // with one k-step per K-tile the fragment slots alternate per tile (the stages' parity)
+            constexpr int kk = decltype(kk_t)::value, slot = (KSTEPS == 1 ? S : kk) & 1;
             constexpr bool last = (kk == KSTEPS - 1);
             if (last) {
                 // a bare s_barrier: __syncthreads() carries a fence, which with LDS-DMA in flight becomes a
                 // full drain of the memory counter.  What the fence would order is ordered by hand: this
-                // wave's DMAs of K-tile +1 have landed (vmcnt), its reads of stage S have returned (lgkmcnt).
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDMA) : "memory");
+                // wave's DMAs of K-tile +1 have landed (vmcnt: the DMAs issued since may be in flight - those
+                // of this tile and the one before, or only the latter when the wait opens the tile), its
+                // reads of stage S have returned (lgkmcnt).
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KSTEPS == 1 ? NDMA : 2 * NDMA) : "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if (kk > 0) frags_wait(std::integral_constant<int, slot>());
+            frags_wait(std::integral_constant<int, slot>());
+            if (kk == 0) {
+                k_wait();  // requested a k-step ago, and the fragment wait has covered it
+                ka = ka_next;
+                kb = kb_next;
+            }
             static_for<0, NMFMA>([&](auto q_t) {
                 constexpr int q = decltype(q_t)::value;
                 acc[q / TN][q % TN] = Tr::mfma(fa[slot][q / TN], fb[slot][q % TN], acc[q / TN][q % TN]);
@@ -326,7 +336,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
                     else read_frags(std::integral_constant<int, slot ^ 1>(), std::integral_constant<int, (kk + 1) % KSTEPS>(), stage_t);
                 }
                 if (kk == 0 && q >= 2 && q < 2 + 3 * NDMA && (q - 2) % 3 == 0) issue((q - 2) / 3, ld, ka, kb);
-                if (last && q == 1) advance();
+                if (last && q == (KSTEPS == 1 ? 2 + 3 * NDMA : 1)) advance();
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
@@ -348,6 +358,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     // tile nobody multiplies) have returned
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     frags_wait(I0());
+    frags_wait(I1());
 
     store_tile<T, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, sid, chunk);
     __syncthreads();  // s_coff and the stages are the next item's
@@ -487,13 +498,17 @@ int dma_gemm_row_bytes(int dtype, int layout_a, int layout_b, int bm, int bn, co
     if (layout_b == 0 && p.kb_in != 1) return 0;
     // an fp32 outer-major lane offset carries one step along k
     if (dtype == 1 && (p.ka_in >= (int64_t(1) << 28) || p.kb_in >= (int64_t(1) << 28))) return 0;
-    if (dtype == 0) return (p.k8_affine && p.K >= 8 && p.K % 8 == 0) ? 64 : 0;
-    if (p.k16_affine && p.K >= 16 && p.K % 16 == 0) return 64;
-    // The 32-byte geometry has a barrier per sixteen MFMAs of 32 cycles per wave: it beats the register-staged
-    // kernel on problems of two rounds of tiles and more (headline contraction in fp32, extent 72: 127 -> 141
-    // TFLOP/s, 88: 130 -> 145) and loses below (extent 56, 625 tiles, mostly cut along K: 118 -> 110).
+    // The 32-byte geometries have a barrier per sixteen MFMAs per wave: they beat the register-staged kernel
+    // on problems of two rounds of tiles and more (headline contraction in fp32, extent 72: 127 -> 141
+    // TFLOP/s, 88: 130 -> 145) and lose below (extent 56, 625 tiles, mostly cut along K: 118 -> 110).
     const int64_t tiles = ((p.M + kBM - 1) / kBM) * ((p.N + kBN - 1) / kBN);
-    return (p.k8_affine && p.K >= 8 && p.K % 8 == 0 && tiles * p.batch >= 1024) ? 32 : 0;
+    const bool large = tiles * p.batch >= 1024;
+    if (dtype == 0) {
+        if (p.k8_affine && p.K >= 8 && p.K % 8 == 0) return 64;
+        return (large && p.k4_affine && p.K >= 4 && p.K % 4 == 0) ? 32 : 0;
+    }
+    if (p.k16_affine && p.K >= 16 && p.K % 16 == 0) return 64;
+    return (large && p.k8_affine && p.K >= 8 && p.K % 8 == 0) ? 32 : 0;
 }
 
 bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
@@ -506,7 +521,9 @@ hipError_t schedule_gemm_dma(int dtype, int layout_a, int layout_b, const GemmPa
 {
     const int rb = dma_gemm_row_bytes(dtype, layout_a, layout_b, kBM, kBN, p);
     if (rb == 0) return hipErrorInvalidValue;
-    if (dtype == 0) return dispatch<double, 64>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr);
+    if (dtype == 0)
+        return rb == 64 ? dispatch<double, 64>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr)
+                        : dispatch<double, 32>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr);
     return rb == 64 ? dispatch<float, 64>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr)
                     : dispatch<float, 32>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr);
 }
@@ -516,7 +533,9 @@ hipError_t launch_gemm_dma(int dtype, int layout_a, int layout_b, const GemmPara
 {
     const int rb = dma_gemm_row_bytes(dtype, layout_a, layout_b, kBM, kBN, p);
     if (rb == 0) return hipErrorInvalidValue;
-    if (dtype == 0) return dispatch<double, 64>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream);
+    if (dtype == 0)
+        return rb == 64 ? dispatch<double, 64>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream)
+                        : dispatch<double, 32>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream);
     return rb == 64 ? dispatch<float, 64>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream)
                     : dispatch<float, 32>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream);
 }

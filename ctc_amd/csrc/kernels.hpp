@@ -39,8 +39,8 @@ struct GemmParams {
     int64_t ka_stride = 0, kb_stride = 0;
     // k8_affine != 0: K is a multiple of 8 and inside every aligned group of 8 the k offsets are affine,
     // k_a[8 g + i] == k_a[8 g] + i * ka_in (likewise k_b, kb_in): a K-tile of 8 needs one table entry
-    // k16_affine, k32_affine: the same for groups of 16 / 32
-    int k8_affine = 0, k16_affine = 0, k32_affine = 0;
+    // k4_affine, k16_affine, k32_affine: the same for groups of 4 / 16 / 32
+    int k4_affine = 0, k8_affine = 0, k16_affine = 0, k32_affine = 0;
     int64_t ka_in = 0, kb_in = 0;
 };
 

@@ -63,7 +63,7 @@ struct Plan {
     // k8_affine: K is a multiple of 8 and inside every aligned group of 8 contracted indices both k tables
     // are affine with steps ka_in / kb_in (true when the fastest contracted mode's extent is a multiple
     // of 8): a kernel that walks K in tiles of 8 needs one table entry per tile
-    bool k8_affine = false, k16_affine = false, k32_affine = false;  // groups of 8 / 16 / 32
+    bool k4_affine = false, k8_affine = false, k16_affine = false, k32_affine = false;  // groups of 4 / 8 / 16 / 32
     int64_t ka_in = 0, kb_in = 0;
     // largest row offset of A / column offset of B (elements)
     int64_t max_row_a = 0, max_col_b = 0;

@@ -57,6 +57,16 @@ CASES = [
     # batch entries run as grid.y
     ("batched", "zak,zkb->zab", dict(z=3, a=1500, b=1400, k=32)),
     ("rank6", "adij,bcdk->abcijk", dict(a=6, b=20, c=20, i=20, j=22, k=8, d=24)),
+    # K (or the k tables' affine groups) a multiple of 4 only: K-tiles of 4, one k-step each (from two rounds
+    # of tiles on)
+    ("k4_nn_kmajor_outer", "ak,kb->ab", dict(a=4100, b=4200, k=44)),
+    ("k4_nt_kmajor_kmajor", "ak,bk->ab", dict(a=4164, b=4032, k=20)),
+    ("k4_tn_outer_outer", "ka,kb->ab", dict(a=4200, b=4100, k=28)),
+    ("k4_tt_outer_kmajor", "ka,bk->ab", dict(a=4036, b=4292, k=12)),
+    ("k4_one_k_tile", "ak,kb->ab", dict(a=4100, b=4200, k=4)),
+    ("k4_five_k_tiles", "ak,bk->ab", dict(a=4100, b=4200, k=20)),
+    ("k4_ccsd_three_by_12", "aeim,ebmj->abij", dict(a=82, b=84, i=50, j=52, e=3, m=12)),
+    ("k4_split_k_tail", "ak,kb->ab", dict(a=4224, b=4480, k=1036)),
 ]
 
 
@@ -120,8 +130,10 @@ def test_which_launches_take_the_dma_kernel(cuda):
     run = lambda spec, ext, a=x: lambda: ctc_amd.Plan(spec, ext, "f64").execute(a, x, c)  # noqa: E731
     big = dict(a=4096, b=4096)
     assert _delta(run("ak,kb->ab", dict(big, k=256))) == (0, 1, 0, 0)
-    assert _delta(run("ak,kb->ab", dict(big, k=260))) == (1, 0, 0, 0)                 # K not a multiple of 8
-    assert _delta(run("aef,feb->ab", dict(big, e=4, f=12))) == (1, 0, 0, 0)            # groups of 8 straddle a mode
+    assert _delta(run("ak,kb->ab", dict(big, k=260))) == (0, 1, 0, 0)                 # K a multiple of 4: K-tiles of 4
+    assert _delta(run("ak,kb->ab", dict(big, k=262))) == (1, 0, 0, 0)                 # K not a multiple of 4
+    assert _delta(run("aef,feb->ab", dict(big, e=4, f=12))) == (0, 1, 0, 0)            # groups of 8 straddle a mode, of 4 do not
+    assert _delta(run("aef,feb->ab", dict(big, e=4, f=10))) == (1, 0, 0, 0)            # groups of 4 straddle a mode
     assert _delta(run("aef,feb->ab", dict(big, e=16, f=8))) == (0, 1, 0, 0)            # they do not
     assert _delta(run("ak,kb->ab", dict(a=512, b=512, k=256))) == (1, 0, 0, 0)         # small tile
     assert _delta(run("ak,kb->ab", dict(big, k=256), x[1:])) == (1, 0, 0, 0)           # unaligned base: element loads
