@@ -41,8 +41,9 @@ using namespace lds_dma;
 
 constexpr int kBM = 128, kBN = 128, kStages = 4;
 // RB: bytes of k per row of a K-tile.  64 (8 fp64 / 16 fp32 contracted elements) is the geometry described
-// above; 32 (4 fp64 / 8 fp32 elements: one / two k-steps, 8 KB stages, one DMA instruction per wave and
-// operand) is for contractions whose k tables are affine in groups of that many only.
+// above; 32 (images of 4 fp64 / 8 fp32 elements: one / two k-steps, one DMA instruction per wave and image)
+// is for contractions whose k tables are affine in groups of that many only, with one or two images per
+// operand and stage (NSUB of the kernel).
 template <typename T, int RB> constexpr int tile_k() { return RB / (int)sizeof(T); }
 template <int RB> constexpr int op_bytes() { return 128 * RB; }         // one operand's tile image
 template <int RB> constexpr int stage_bytes() { return 2 * op_bytes<RB>(); }  // A image, then B image
@@ -149,18 +150,22 @@ template <typename T, int LAY, int RB> struct Operand {
     }
 };
 
-template <typename T, int LA, int LB, int RB>
+// NSUB: images per operand and stage.  2 (with RB = 32) puts two K-tiles of 32-byte rows, each with its own k
+// offset, into one stage: the K loop then has the shape of the 64-byte geometry (one barrier per 32 MFMAs per
+// wave) for k tables that are affine in groups of half a K-tile only.
+template <typename T, int LA, int LB, int RB, int NSUB>
 __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
 {
-    constexpr int BM = kBM, BN = kBN, BK = tile_k<T, RB>(), WN = 2;
-    constexpr int kOpBytes = op_bytes<RB>(), kStageBytes = stage_bytes<RB>();
-    constexpr int TM = 4, TN = 4, NMFMA = TM * TN, KSTEPS = BK / 4;
+    static_assert(NSUB == 1 || (NSUB == 2 && RB == 32), "two sub-tiles only with 32-byte rows");
+    constexpr int BM = kBM, BN = kBN, BKS = tile_k<T, RB>(), BK = NSUB * BKS, WN = 2;
+    constexpr int kOpBytes = op_bytes<RB>(), kOperandBytes = NSUB * kOpBytes, kStageBytes = 2 * kOperandBytes;
+    constexpr int TM = 4, TN = 4, NMFMA = TM * TN, KSTEPS = BK / 4, KS1 = BKS / 4;  // k-steps per stage / per image
     static_assert(KSTEPS == 1 || KSTEPS % 2 == 0, "fragment slots alternate per k-step (per K-tile when it has one k-step)");
     typedef Traits<T> Tr;
     typedef typename Tr::acc_t acc_t;
     typedef Operand<T, LA, RB> OA;
     typedef Operand<T, LB, RB> OB;
-    constexpr int NI = OA::NI, NDMA = 2 * NI;  // DMA instructions per wave per K-tile
+    constexpr int NI = OA::NI, NDMA = 2 * NSUB * NI;  // DMA instructions per wave per stage
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[kStages * kStageBytes];
     __shared__ int64_t s_coff[BM + BN];
@@ -232,7 +237,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     ob.init_dma(p.col_b, n0, p.N, p.kb_in, lane, wave);
     const unsigned smem_lds = lds_addr(smem);
     oa.init_frag(smem_lds, frow, fk, wm0);
-    ob.init_frag(smem_lds + kOpBytes, frow, fk, wn0);
+    ob.init_frag(smem_lds + kOperandBytes, frow, fk, wn0);
 
     acc_t acc[TM][TN];
 #pragma unroll
@@ -245,24 +250,31 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     // Its k offsets come by SCALAR loads issued from assembly (the compiler would take vector loads here,
     // whose first use drains every DMA in flight); asynchronous: k_wait() before the first use.
     int tl = 0;  // tile the next request is for, relative to kt_first
-    int64_t ka_next, kb_next;
+    int64_t ka_next[NSUB], kb_next[NSUB];  // one k offset per image
     auto k_fetch = [&]() {
-        const int64_t *pa = p.k_a + (int64_t)(kt_first + tl) * BK, *pb = p.k_b + (int64_t)(kt_first + tl) * BK;
-        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(ka_next) : "s"(pa));
-        asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(kb_next) : "s"(pb));
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int64_t *pa = p.k_a + (int64_t)(kt_first + tl) * BK + sub * BKS, *pb = p.k_b + (int64_t)(kt_first + tl) * BK + sub * BKS;
+            asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(ka_next[sub]) : "s"(pa));
+            asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(kb_next[sub]) : "s"(pb));
+        }
     };
-    auto k_wait = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ka_next), "+s"(kb_next)); };
+    auto k_wait = [&]() {
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ka_next[sub]), "+s"(kb_next[sub]));
+    };
     auto advance = [&]() {
         tl = (tl + 1 == nk) ? 0 : tl + 1;
         k_fetch();
     };
     k_fetch();
     k_wait();
-    // instruction u (the first NI: A, then B) of the requested tile into stage `stage`
-    auto issue = [&](int u, unsigned stage, int64_t ka, int64_t kb) {  // stage: LDS address
-        const int j = u % NI;
-        if (u < NI) dma16_split(A + OA::uniform(ka, p.ka_in, wave, j), oa.off[j], stage + (NI * wave + j) * 1024);
-        else dma16_split(B + OB::uniform(kb, p.kb_in, wave, j), ob.off[j], stage + kOpBytes + (NI * wave + j) * 1024);
+    // instruction u (A's images one after the other, then B's) of the requested tile into stage `stage`
+    auto issue = [&](int u, unsigned stage, const int64_t (&ka)[NSUB], const int64_t (&kb)[NSUB]) {  // stage: LDS address
+        const int opnd = u / (NSUB * NI), sub = (u % (NSUB * NI)) / NI, j = u % NI;
+        const unsigned dst = stage + opnd * kOperandBytes + sub * kOpBytes + (NI * wave + j) * 1024;
+        if (opnd == 0) dma16_split(A + OA::uniform(ka[sub], p.ka_in, wave, j), oa.off[j], dst);
+        else dma16_split(B + OB::uniform(kb[sub], p.kb_in, wave, j), ob.off[j], dst);
     };
     __syncthreads();  // s_coff is written; no DMA is in flight yet
 #pragma unroll
@@ -279,13 +291,14 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     // fragments of k-step KK of stage S into slot SLOT; asynchronous (frags_wait)
     auto read_frags = [&](auto slot_t, auto kk_t, auto stage_t) {
         constexpr int SLOT = decltype(slot_t)::value, KK = decltype(kk_t)::value, S = decltype(stage_t)::value;
+        constexpr int SUB = KK / KS1, K1 = KK % KS1;  // image, k-step inside it
         static_for<0, TM>([&](auto b_t) {
             constexpr int b = decltype(b_t)::value;
-            lds_read<S * kStageBytes + OA::template frag_imm<b, KK>()>(fa[SLOT][b], oa.template frag_reg<b, KK>());
+            lds_read<S * kStageBytes + SUB * kOpBytes + OA::template frag_imm<b, K1>()>(fa[SLOT][b], oa.template frag_reg<b, K1>());
         });
         static_for<0, TN>([&](auto b_t) {
             constexpr int b = decltype(b_t)::value;
-            lds_read<S * kStageBytes + OB::template frag_imm<b, KK>()>(fb[SLOT][b], ob.template frag_reg<b, KK>());
+            lds_read<S * kStageBytes + SUB * kOpBytes + OB::template frag_imm<b, K1>()>(fb[SLOT][b], ob.template frag_reg<b, K1>());
         });
     };
     auto frags_wait = [&](auto slot_t) {
@@ -308,7 +321,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     auto tile_step = [&](auto stage_t) {
         constexpr int S = decltype(stage_t)::value, SN = (S + 1) % kStages, SL = (S + kStages - 1) % kStages;
         const unsigned ld = smem_lds + SL * kStageBytes;
-        int64_t ka = 0, kb = 0;
+        int64_t ka[NSUB], kb[NSUB];
         static_for<0, KSTEPS>([&](auto kk_t) {
             // with one k-step per K-tile the fragment slots alternate per tile (the stages' parity)
             constexpr int kk = decltype(kk_t)::value, slot = (KSTEPS == 1 ? S : kk) & 1;
@@ -325,8 +338,11 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
             frags_wait(std::integral_constant<int, slot>());
             if (kk == 0) {
                 k_wait();  // requested a k-step ago, and the fragment wait has covered it
-                ka = ka_next;
-                kb = kb_next;
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) {
+                    ka[sub] = ka_next[sub];
+                    kb[sub] = kb_next[sub];
+                }
             }
             static_for<0, NMFMA>([&](auto q_t) {
                 constexpr int q = decltype(q_t)::value;
@@ -371,7 +387,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
 #endif
 }
 
-template <typename T, int LA, int LB, int RB> int resident_slots()
+template <typename T, int LA, int LB, int RB, int NSUB> int resident_slots()
 {
     static std::atomic<int> cache[64];  // 0: not queried yet; host threads of several devices may race here
     int dev = 0;
@@ -379,7 +395,7 @@ template <typename T, int LA, int LB, int RB> int resident_slots()
     if (cache[dev].load() == 0) {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<T, LA, LB, RB>, 256, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<T, LA, LB, RB, NSUB>, 256, 0) != hipSuccess) return 0;
         cache[dev].store(cus * per_cu > 0 ? cus * per_cu : -1);
     }
     const int slots = cache[dev].load();
@@ -407,9 +423,9 @@ int best_split(int64_t tail, int slots, int nk, int min_chunk_tiles)
     return best_f;
 }
 
-template <typename T, int LA, int LB, int RB> hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
+template <typename T, int LA, int LB, int RB, int NSUB> hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
 {
-    constexpr int BK = tile_k<T, RB>();
+    constexpr int BK = NSUB * tile_k<T, RB>();
     GemmSchedule s;
     s.nbm = (int)((p.M + kBM - 1) / kBM);
     s.nbn = (int)((p.N + kBN - 1) / kBN);
@@ -420,7 +436,7 @@ template <typename T, int LA, int LB, int RB> hipError_t schedule_one(const Gemm
     s.tail_tiles = 0;
     s.ws_bytes = 0;
     static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
-    const int slots = resident_slots<T, LA, LB, RB>();
+    const int slots = resident_slots<T, LA, LB, RB, NSUB>();
     const int nk = (int)(p.K / BK);
     if (!no_split && slots > 0 && p.batch == 1) {
         const int tail = (int)(tiles % slots);
@@ -438,7 +454,7 @@ template <typename T, int LA, int LB, int RB> hipError_t schedule_one(const Gemm
     return hipSuccess;
 }
 
-template <typename T, int LA, int LB, int RB>
+template <typename T, int LA, int LB, int RB, int NSUB>
 hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     GemmParams q = p;
@@ -457,11 +473,11 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     // CTC_TC_DMA_PERSIST=0 / 1: never / whenever there are more items than slots.
     static const int persist = getenv("CTC_TC_DMA_PERSIST") ? atoi(getenv("CTC_TC_DMA_PERSIST")) : -1;
     if (persist != 0) {
-        const unsigned slots = (unsigned)resident_slots<T, LA, LB, RB>();
+        const unsigned slots = (unsigned)resident_slots<T, LA, LB, RB, NSUB>();
         if (slots >= 8 && slots % 8 == 0 && items > slots && (persist == 1 || (sizeof(T) == 8 && items >= 4 * slots))) items = slots;
     }
     dim3 grid(items, (unsigned)p.batch, 1);
-    hipLaunchKernelGGL((gemm_dma_kernel<T, LA, LB, RB>), grid, dim3(256), 0, stream, q);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, LA, LB, RB, NSUB>), grid, dim3(256), 0, stream, q);
     if (sch.tail_tiles > 0) {
         hipError_t e = launch_splitk_fixup_128(sizeof(T) == 8 ? 0 : 1, q, sch.tail_tiles, stream);
         if (e != hipSuccess) return e;
@@ -469,12 +485,12 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     return hipGetLastError();
 }
 
-template <typename T, int RB>
+template <typename T, int RB, int NSUB>
 hipError_t dispatch(int layout_a, int layout_b, const GemmParams &p, GemmSchedule *sch_out, const GemmSchedule *sch_in,
                     void *ws, hipStream_t stream)
 {
 #define CTC_CASE(A_, B_) \
-    case A_ * 2 + B_: return sch_out ? schedule_one<T, A_, B_, RB>(p, sch_out) : launch_one<T, A_, B_, RB>(p, *sch_in, ws, stream);
+    case A_ * 2 + B_: return sch_out ? schedule_one<T, A_, B_, RB, NSUB>(p, sch_out) : launch_one<T, A_, B_, RB, NSUB>(p, *sch_in, ws, stream);
     switch (layout_a * 2 + layout_b) {
         CTC_CASE(0, 0) CTC_CASE(0, 1) CTC_CASE(1, 0) CTC_CASE(1, 1)
     default: return hipErrorInvalidValue;
@@ -482,10 +498,10 @@ hipError_t dispatch(int layout_a, int layout_b, const GemmParams &p, GemmSchedul
 #undef CTC_CASE
 }
 
-}  // namespace
-
-// bytes of k per row of the K-tile the launch takes (64 or, fp32 only, 32), 0: the launch does not qualify
-int dma_gemm_row_bytes(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
+// The geometry the launch takes: 0 none (it does not qualify), 1: 64-byte rows, 2: two images of 32-byte rows
+// per stage (k tables affine in groups of half a K-tile), 3: one image of 32-byte rows (K a multiple of half
+// a K-tile only)
+int dma_gemm_geometry(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
 {
     static const bool off = getenv("CTC_TC_NO_DMA_GEMM") != nullptr;
     if (off || bm != kBM || bn != kBN || (dtype != 0 && dtype != 1)) return 0;
@@ -498,46 +514,50 @@ int dma_gemm_row_bytes(int dtype, int layout_a, int layout_b, int bm, int bn, co
     if (layout_b == 0 && p.kb_in != 1) return 0;
     // an fp32 outer-major lane offset carries one step along k
     if (dtype == 1 && (p.ka_in >= (int64_t(1) << 28) || p.kb_in >= (int64_t(1) << 28))) return 0;
-    // The 32-byte geometries have a barrier per sixteen MFMAs per wave: they beat the register-staged kernel
-    // on problems of two rounds of tiles and more (headline contraction in fp32, extent 72: 127 -> 141
-    // TFLOP/s, 88: 130 -> 145) and lose below (extent 56, 625 tiles, mostly cut along K: 118 -> 110).
+    const int bk = dtype == 0 ? 8 : 16;  // K-tile of the 64-byte geometry
+    const bool full = dtype == 0 ? p.k8_affine != 0 : p.k16_affine != 0;
+    const bool half = dtype == 0 ? p.k4_affine != 0 : p.k8_affine != 0;
+    if (full && p.K >= bk && p.K % bk == 0) return 1;
+    if (half && p.K >= bk && p.K % bk == 0) return 2;
+    // One image of 32-byte rows has a barrier per sixteen MFMAs per wave: it beats the register-staged kernel
+    // on problems of two rounds of tiles and more and loses below (fp32, 625 tiles mostly cut along K: 118 -> 110).
     const int64_t tiles = ((p.M + kBM - 1) / kBM) * ((p.N + kBN - 1) / kBN);
-    const bool large = tiles * p.batch >= 1024;
-    if (dtype == 0) {
-        if (p.k8_affine && p.K >= 8 && p.K % 8 == 0) return 64;
-        return (large && p.k4_affine && p.K >= 4 && p.K % 4 == 0) ? 32 : 0;
-    }
-    if (p.k16_affine && p.K >= 16 && p.K % 16 == 0) return 64;
-    return (large && p.k8_affine && p.K >= 8 && p.K % 8 == 0) ? 32 : 0;
+    return (half && p.K >= bk / 2 && p.K % (bk / 2) == 0 && tiles * p.batch >= 1024) ? 3 : 0;
 }
+
+template <typename T>
+hipError_t dispatch_geometry(int g, int la, int lb, const GemmParams &p, GemmSchedule *sch_out, const GemmSchedule *sch_in, void *ws,
+                             hipStream_t stream)
+{
+    switch (g) {
+    case 1: return dispatch<T, 64, 1>(la, lb, p, sch_out, sch_in, ws, stream);
+    case 2: return dispatch<T, 32, 2>(la, lb, p, sch_out, sch_in, ws, stream);
+    case 3: return dispatch<T, 32, 1>(la, lb, p, sch_out, sch_in, ws, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
 
 bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
 {
-    return dma_gemm_row_bytes(dtype, layout_a, layout_b, bm, bn, p) != 0;
+    return dma_gemm_geometry(dtype, layout_a, layout_b, bm, bn, p) != 0;
 }
 
 // bm / bn are the 128 x 128 tile here: the callers have asked dma_gemm_supported
 hipError_t schedule_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out)
 {
-    const int rb = dma_gemm_row_bytes(dtype, layout_a, layout_b, kBM, kBN, p);
-    if (rb == 0) return hipErrorInvalidValue;
-    if (dtype == 0)
-        return rb == 64 ? dispatch<double, 64>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr)
-                        : dispatch<double, 32>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr);
-    return rb == 64 ? dispatch<float, 64>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr)
-                    : dispatch<float, 32>(layout_a, layout_b, p, out, nullptr, nullptr, nullptr);
+    const int g = dma_gemm_geometry(dtype, layout_a, layout_b, kBM, kBN, p);
+    return dtype == 0 ? dispatch_geometry<double>(g, layout_a, layout_b, p, out, nullptr, nullptr, nullptr)
+                      : dispatch_geometry<float>(g, layout_a, layout_b, p, out, nullptr, nullptr, nullptr);
 }
 
 hipError_t launch_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
                            void *workspace, hipStream_t stream)
 {
-    const int rb = dma_gemm_row_bytes(dtype, layout_a, layout_b, kBM, kBN, p);
-    if (rb == 0) return hipErrorInvalidValue;
-    if (dtype == 0)
-        return rb == 64 ? dispatch<double, 64>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream)
-                        : dispatch<double, 32>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream);
-    return rb == 64 ? dispatch<float, 64>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream)
-                    : dispatch<float, 32>(layout_a, layout_b, p, nullptr, &schedule, workspace, stream);
+    const int g = dma_gemm_geometry(dtype, layout_a, layout_b, kBM, kBN, p);
+    return dtype == 0 ? dispatch_geometry<double>(g, layout_a, layout_b, p, nullptr, &schedule, workspace, stream)
+                      : dispatch_geometry<float>(g, layout_a, layout_b, p, nullptr, &schedule, workspace, stream);
 }
 
 }  // namespace ctc

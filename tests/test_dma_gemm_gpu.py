@@ -66,6 +66,12 @@ CASES = [
     ("k4_one_k_tile", "ak,kb->ab", dict(a=4100, b=4200, k=4)),
     ("k4_five_k_tiles", "ak,bk->ab", dict(a=4100, b=4200, k=20)),
     ("k4_ccsd_three_by_12", "aeim,ebmj->abij", dict(a=82, b=84, i=50, j=52, e=3, m=12)),
+    # K a multiple of 8 but the k tables affine in groups of 4 only: two images of 32-byte rows per stage
+    ("k4x2_ccsd_four_by_12", "aeim,ebmj->abij", dict(a=52, b=50, i=50, j=52, e=4, m=12)),
+    ("k4x2_ccsd_other_layouts", "eaim,jbem->abij", dict(a=48, b=50, i=54, j=52, e=6, m=4)),
+    ("k4x2_modes_do_not_fuse", "aef,feb->ab", dict(a=2600, b=2500, e=6, f=12)),
+    ("k4x2_outer_operands", "efa,feb->ab", dict(a=2600, b=2500, e=6, f=12)),
+    ("k4x2_split_k_tail", "aef,feb->ab", dict(a=1024, b=1152, e=340, f=12)),
     ("k4_split_k_tail", "ak,kb->ab", dict(a=4224, b=4480, k=1036)),
 ]
 
@@ -78,6 +84,10 @@ F32_CASES = [
     ("k8_tt_outer_kmajor", "ka,bk->ab", dict(a=4036, b=4292, k=24)),
     ("k8_one_k_tile", "ak,kb->ab", dict(a=4100, b=4200, k=8)),
     ("k8_ccsd_three_by_24", "aeim,ebmj->abij", dict(a=82, b=84, i=50, j=52, e=3, m=24)),
+    ("k8x2_ccsd_two_by_24", "aeim,ebmj->abij", dict(a=52, b=50, i=50, j=52, e=2, m=24)),
+    ("k8x2_modes_do_not_fuse", "aef,feb->ab", dict(a=2600, b=2500, e=6, f=24)),
+    ("k8x2_outer_operands", "efa,feb->ab", dict(a=2600, b=2500, e=6, f=24)),
+    ("k8x2_split_k_tail", "aef,feb->ab", dict(a=1024, b=1152, e=170, f=24)),
     ("k8_split_k_tail", "ka,bk->ab", dict(a=4224, b=4480, k=1032)),
     ("nn_kmajor_outer", "ak,kb->ab", dict(a=2500, b=2600, k=64)),
     ("nt_kmajor_kmajor", "ak,bk->ab", dict(a=2564, b=2432, k=48)),
