@@ -69,7 +69,8 @@ bool stream_gemm_f64_dma_supported(int layout_a, int layout_b, const GemmParams 
 hipError_t launch_gemm_stream_f64_dma(int layout_a, int layout_b, const GemmParams &p, hipStream_t stream);
 
 // fp64 / fp32, 128 x 128 tiles, operands staged by LDS-DMA (gemm_dma_kernels.hip); schedule_gemm / launch_gemm
-// route to it when dma_gemm_supported says the launch qualifies (vector layouts, k8_affine / k16_affine).
+// route to it when dma_gemm_supported says the launch qualifies (vector layouts, k tables affine in aligned
+// groups of at least half a K-tile: k4_affine / k8_affine / k16_affine).
 bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p);
 hipError_t schedule_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out);
 hipError_t launch_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,

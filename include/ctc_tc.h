@@ -129,9 +129,10 @@ const char *ctc_tc_last_error(void);
  *   "stream_max_k"  largest K the automatic choice sends to the persistent kernel (default 128; fp32: at most 96);
  *   "stream_f64_dma" 1 (default): fp64 launches that qualify (even M and N, one stride per operand along
  *                   K) take the persistent kernel's LDS-DMA form; 0: its register-staged form;
- *   "dma_gemm"      1 (default): fp64 one-tile-per-workgroup launches whose operands both have a
- *                   16-byte-vector layout and whose k offsets are affine inside every aligned group of 8
- *                   (K a multiple of 8) stage their operands by LDS-DMA; 0: always through registers.
+ *   "dma_gemm"      1 (default): fp64 / fp32 launches on the 128 x 128 tile whose operands both have a
+ *                   16-byte-vector layout and whose k offsets are affine inside every aligned group of 4
+ *                   (fp64) or 8 (fp32) contracted indices, K a multiple of that, stage their operands by
+ *                   LDS-DMA; 0: always through registers.
  * No reference counterpart.
  */
 int ctc_tc_set_option(const char *name, int64_t value);
