@@ -2,6 +2,8 @@
 fp32 contracted elements) against the CPU oracle and against the register-staged kernel, through the C ABI.  Both kernels add the products of
 their K-tiles in k order into the same accumulators, so the two agree to the parity tolerance (1e-12 fp64 /
 1e-5 fp32 of max |C|); index and table outputs are the planner's and are compared bit for bit elsewhere."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -197,7 +199,7 @@ def test_seeded_random_contractions_on_large_tiles(cuda, oracle):
     import random
     rng = random.Random(0xD3A)
     took_dma = 0
-    n_cases = 30
+    n_cases = int(os.environ.get("CTC_DMA_FUZZ_CASES", "30"))
     for n in range(n_cases):
         dtype = rng.choice(["f64", "f64", "f32"])
         ext = dict(a=rng.choice([56, 60, 66]), i=rng.choice([48, 56, 64]),
