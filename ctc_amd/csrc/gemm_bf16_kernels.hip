@@ -558,13 +558,25 @@ __global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(co
 }
 
 // ---- ring kernel ---------------------------------------------------------------------------------------
-// The 256 x 256 tile for two K-major operands with the staging of gemm_dma_kernels.hip: K-tiles of 32 (64-byte
-// rows, one MFMA k-step) in a ring of four 32 KB stages, the DMAs of K-tile t + 4 issued during K-tile t,
+// The 256 x 256 tile for two 16-byte-vector operands with the staging of gemm_dma_kernels.hip: K-tiles of 32
+// (one MFMA k-step) in a ring of four 32 KB stages, the DMAs of K-tile t + 4 issued during K-tile t,
 // K-tile t + 1 awaited with a counted s_waitcnt before the one bare barrier of the tile, fragment reads
-// (ds_read_b128, the next tile's while this tile's MFMAs run) and DMAs issued from assembly so that neither
+// (the next tile's while this tile's MFMAs run) and DMAs issued from assembly so that neither
 // the compiler's waits nor the vector ALU are involved.  The two-buffer kernel above waits for a DMA one
 // K-tile (0.9 us of MFMAs) after issuing it, which is less than the transfer takes under load.
-// Image [row][32 k], chunk c (8 k) of row r at chunk position c ^ ((r >> 2) & 3).
+// Images of one operand's K-tile (16 KB either way):
+//   K-major  [row][32 k], 64-byte rows, chunk c (8 k) of row r at chunk position c ^ (-(r >> 2) & 3);
+//            a fragment is one ds_read_b128.  The sixteen lanes a ds_read_b128 services together hold rows
+//            m, 12 + m (chunk kg) and 4 + m, 8 + m (chunk kg ^ 1), m = 0 .. 3; rows with equal m share a
+//            64-byte quarter of the 256-byte bank row, and the XOR terms 0, 3, 2, 1 of the four row groups
+//            put their chunks on its four different slots (c ^ ((r >> 2) & 3) is 2-way conflicting: measured
+//            6 against 3 LDS clocks per read, tools/lds_read_probe.hip).
+//   outer    [k][256 rows], 512-byte lines, chunk c (8 rows) of line k at chunk position
+//            c ^ (((k & 3) << 2) | (((k >> 3) & 1) << 1)); a fragment is two ds_read_b64_tr_b16 (lines
+//            8 g + 0..3 and 8 g + 4..7 of lane group g).  The eight lines a 32-lane half reads together
+//            (q = 0..3 of two lane groups) have eight different XOR terms, so their 32-byte pieces of one
+//            16-row block fall on eight different bank groups; the term is the same for lines k and k + 4,
+//            which makes the second read of a fragment the first one's address + 2048.
 constexpr int kRingBK = 32, kRingStages = 4;
 constexpr int kRingImage = 256 * kRingBK * 2;  // one operand's tile image
 constexpr int kRingStage = 2 * kRingImage;
@@ -574,14 +586,104 @@ template <int OFF> __device__ __forceinline__ void lds_read128(u4_t &d, unsigned
     static_assert(OFF >= 0 && OFF < 65536 && OFF % 16 == 0, "ds_read offset field");
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
-__device__ __forceinline__ void lds_wait12(u4_t (&a)[8], u4_t (&b)[4])
+// The two transposing reads of one outer-image fragment at (addr ^ XOR) + OFF and 2048 bytes behind.  The XOR is
+// formed here, next to the reads, so that the compiler does not keep one address register per block alive
+// across the whole K loop (the kernel has no registers to spare).
+template <int OFF, int XOR> __device__ __forceinline__ void lds_read_tr64x2(u2_t &lo, u2_t &hi, unsigned addr)
 {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]),
-                   "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    static_assert(OFF >= 0 && OFF + 2048 < 65536 && OFF % 8 == 0, "ds_read offset field");
+    unsigned tmp;
+    asm volatile("v_xor_b32 %2, %4, %3\n\tds_read_b64_tr_b16 %0, %2 offset:%5\n\tds_read_b64_tr_b16 %1, %2 offset:%6"
+                 : "=&v"(lo), "=&v"(hi), "=&v"(tmp)
+                 : "v"(addr), "n"(XOR), "n"(OFF), "n"(OFF + 2048));
 }
+// Values read from assembly pass through here after the s_waitcnt that covers them and before their first
+// use: the (empty) statement keeps every use behind that wait.
+template <typename V> __device__ __forceinline__ void arrived(V &v) { asm volatile("" : "+v"(v)); }
 
-__global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams p)
+// One operand of the ring kernel as a wave sees it: NB blocks of 16 rows starting at tile row w0.
+// init(): tab = the operand's row table, r0 = the tile's first row, R = its extent, k_in = the element step of
+// its k table inside a K-tile, image = LDS address of the operand's image in stage 0.
+// off[j]: byte offset of this lane's 16 bytes from the K-tile's base, wave instruction j of two (instruction
+// 2 wave + j fills bytes [(2 wave + j) KB, + 1 KB) of the image); rows past the extent repeat rows inside it
+// (their products are never stored).
+template <int LAY, int NB> struct RingOperand;
+
+template <int NB> struct RingOperand<0, NB> {
+    unsigned off[2];
+    unsigned addr[2];  // per pair of stages: the offset field of ds_read holds 64 KB
+    u4_t frag[2][NB];
+    __device__ __forceinline__ void init(const int64_t *__restrict__ tab, int64_t r0, int64_t R, int64_t, unsigned image, int w0,
+                                         int wave, int lane)
+    {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 16 * (2 * wave + j) + (lane >> 2);  // 16 rows of 4 chunks per instruction
+            const int c = (lane & 3) ^ ((0 - (lane >> 4)) & 3);  // the row's XOR term: (row >> 2) & 3 = (lane >> 4) & 3
+            int64_t g = r0 + row;
+            if (g > R - 1) g = R - 1;
+            off[j] = (unsigned)(tab[g] * 2 + c * 16);
+        }
+        const int frow = lane & 15, kg = lane >> 4;  // lane (frow, kg) reads chunk kg of its row
+#pragma unroll
+        for (int h = 0; h < 2; ++h) addr[h] = image + 2 * h * kRingStage + (w0 + frow) * 64 + ((kg ^ ((0 - (frow >> 2)) & 3)) << 4);
+    }
+    template <int SLOT, int S, int B> __device__ __forceinline__ void read()
+    {
+        lds_read128<(S & 1) * kRingStage + B * 1024>(frag[SLOT][B], addr[S >> 1]);
+    }
+    template <int SLOT> __device__ __forceinline__ void all_arrived()
+    {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) arrived(frag[SLOT][b]);
+    }
+    template <int SLOT, int B> __device__ __forceinline__ bf8_t get() const { return __builtin_bit_cast(bf8_t, frag[SLOT][B]); }
+};
+
+template <int NB> struct RingOperand<1, NB> {
+    unsigned off[2];
+    unsigned addr[2];  // block 0, per pair of stages; block b is at addr ^ 32 b (the XOR term of the swizzle mixes with the block index)
+    u2_t lo[2][NB], hi[2][NB];
+    __device__ __forceinline__ void init(const int64_t *__restrict__ tab, int64_t r0, int64_t R, int64_t k_in, unsigned image,
+                                         int w0, int wave, int lane)
+    {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int line = 2 * (2 * wave + j) + (lane >> 5);  // 2 lines of 32 chunks per instruction
+            const int c = (lane & 31) ^ (((line & 3) << 2) | (((line >> 3) & 1) << 1));
+            int64_t g = r0 + 8 * c;
+            if (g > R - 8) g = R - 8;  // R is a multiple of 8 with this layout
+            off[j] = (unsigned)((tab[g] + line * k_in) * 2);
+        }
+        // lane 4 q + pp of lane group g names rows 4 pp .. 4 pp + 3 of line 8 g + q of the block and receives the
+        // four lines of row (lane & 15)
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const unsigned lane_off = 512 * (8 * g + q) + 8 * pp, y32 = 32 * (2 * q + (g & 1));
+        // image and stage addresses are multiples of 1 KB, w0 of 16 NB: bits 5 .. 8 of the address hold
+        // (w0 / 16 + b) ^ (y32 / 32) and nothing else
+#pragma unroll
+        for (int h = 0; h < 2; ++h) addr[h] = image + 2 * h * kRingStage + lane_off + ((unsigned)(2 * w0) ^ y32);
+    }
+    template <int SLOT, int S, int B> __device__ __forceinline__ void read()
+    {
+        lds_read_tr64x2<(S & 1) * kRingStage, 32 * B>(lo[SLOT][B], hi[SLOT][B], addr[S >> 1]);
+    }
+    template <int SLOT> __device__ __forceinline__ void all_arrived()
+    {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            arrived(lo[SLOT][b]);
+            arrived(hi[SLOT][b]);
+        }
+    }
+    template <int SLOT, int B> __device__ __forceinline__ bf8_t get() const
+    {
+        const u4_t both = {lo[SLOT][B][0], lo[SLOT][B][1], hi[SLOT][B][0], hi[SLOT][B][1]};
+        return __builtin_bit_cast(bf8_t, both);
+    }
+};
+
+template <int LA, int LB> __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams p)
 {
     using namespace lds_dma;
     constexpr int BT = 256, BM = BT, BN = BT, TM = 8, TN = 4, NMFMA = TM * TN, NDMA = 4, BK = kRingBK;
@@ -591,7 +693,6 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm0 = (wave / 4) * (16 * TM), wn0 = (wave % 4) * 64;
-    const int frow = lane & 15, kg = lane >> 4;
 #ifdef CTC_CLOCK  // diagnostic build: shader clock while this workgroup runs = core-clock ticks / 100 MHz ticks
     const unsigned long long ck_core0 = __builtin_readcyclecounter(), ck_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -628,28 +729,11 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
     const int kt_last = partial ? (int)((int64_t)(chunk + 1) * nk_total / p.split) : nk_total;
     const int nk = kt_last - kt_first;
 
-    // DMA: instruction j of wave w fills bytes [(2 w + j) KB, + 1 KB) of an image: 16 rows of 4 chunks
-    unsigned off_a[2], off_b[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 16 * (2 * wave + j) + (lane >> 2);
-        const int c = (lane & 3) ^ ((lane >> 4) & 3);
-        int64_t ga = m0 + row, gb = n0 + row;
-        if (ga > p.M - 1) ga = p.M - 1;  // rows past the extent repeat its last row: products never stored
-        if (gb > p.N - 1) gb = p.N - 1;
-        off_a[j] = (unsigned)(p.row_a[ga] * 2 + c * 16);
-        off_b[j] = (unsigned)(p.col_b[gb] * 2 + c * 16);
-    }
-    // fragments: lane (frow, kg) reads chunk kg of its row; one address register per pair of stages (the
-    // offset field of ds_read holds 64 KB)
     const unsigned smem_lds = lds_addr(smem);
-    const unsigned swz = (unsigned)((kg ^ ((frow >> 2) & 3)) << 4);
-    unsigned fra[2], frb[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        fra[h] = smem_lds + 2 * h * kRingStage + (wm0 + frow) * 64 + swz;
-        frb[h] = smem_lds + 2 * h * kRingStage + kRingImage + (wn0 + frow) * 64 + swz;
-    }
+    RingOperand<LA, TM> opa;
+    RingOperand<LB, TN> opb;
+    opa.init(p.row_a, m0, p.M, p.ka_in, smem_lds, wm0, wave, lane);
+    opb.init(p.col_b, n0, p.N, p.kb_in, smem_lds + kRingImage, wn0, wave, lane);
 
     f4_t acc[TM][TN];
 #pragma unroll
@@ -674,8 +758,8 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
     };
     auto issue = [&](int u, unsigned stage, int64_t ka, int64_t kb) {  // stage: LDS address
         const int j = u & 1;
-        if (u < 2) dma16_split(A + ka * 2, off_a[j], stage + (2 * wave + j) * 1024);
-        else dma16_split(B + kb * 2, off_b[j], stage + kRingImage + (2 * wave + j) * 1024);
+        if (u < 2) dma16_split(A + ka * 2, opa.off[j], stage + (2 * wave + j) * 1024);
+        else dma16_split(B + kb * 2, opb.off[j], stage + kRingImage + (2 * wave + j) * 1024);
     };
     k_fetch();
     k_wait();
@@ -689,27 +773,15 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMA) : "memory");  // K-tile 0 has landed
     __builtin_amdgcn_s_barrier();
 
-    u4_t fa[2][TM], fb[2][TN];
-    auto read_frags = [&](auto slot_t, auto stage_t) {
-        constexpr int SLOT = decltype(slot_t)::value, S = decltype(stage_t)::value;
-        static_for<0, TM>([&](auto b_t) {
-            constexpr int b = decltype(b_t)::value;
-            lds_read128<(S & 1) * kRingStage + b * 1024>(fa[SLOT][b], fra[S >> 1]);
-        });
-        static_for<0, TN>([&](auto b_t) {
-            constexpr int b = decltype(b_t)::value;
-            lds_read128<(S & 1) * kRingStage + b * 1024>(fb[SLOT][b], frb[S >> 1]);
-        });
-    };
-    // the same, one fragment at a time (R: 0 .. 7 A row blocks, 8 .. 11 B column blocks): a ds_read_b128 moves
-    // 1 KB and an MFMA lasts 16 cycles, so the twelve reads of a tile are dealt out behind its MFMAs instead of
-    // standing in front of the second one
+    // fragment R of a tile (0 .. 7: A's row blocks, 8 .. 11: B's column blocks) out of stage S into register set
+    // SLOT.  A ds_read_b128 moves 1 KB and an MFMA lasts 16 cycles, so the reads of a tile are dealt out behind
+    // the MFMAs of the previous one instead of standing in front of its second MFMA.
     auto read_one = [&](auto slot_t, auto stage_t, auto r_t) {
         constexpr int SLOT = decltype(slot_t)::value, S = decltype(stage_t)::value, R = decltype(r_t)::value;
-        if constexpr (R < TM) lds_read128<(S & 1) * kRingStage + R * 1024>(fa[SLOT][R], fra[S >> 1]);
-        else lds_read128<(S & 1) * kRingStage + (R - TM) * 1024>(fb[SLOT][R - TM], frb[S >> 1]);
+        if constexpr (R < TM) opa.template read<SLOT, S, R>();
+        else opb.template read<SLOT, S, R - TM>();
     };
-    read_frags(std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+    static_for<0, TM + TN>([&](auto r_t) { read_one(std::integral_constant<int, 0>(), std::integral_constant<int, 0>(), r_t); });
 
     // One K-tile out of stage S (its fragments were requested during the previous tile): wait (K-tile + 1 has
     // landed: the eight DMAs issued since may be in flight; this wave's fragment reads have returned),
@@ -719,28 +791,24 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
         constexpr int S = decltype(stage_t)::value, SN = (S + 1) % kRingStages, slot = S & 1;
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDMA) : "memory");
         __builtin_amdgcn_s_barrier();
-        lds_wait12(fa[slot], fb[slot]);
+        opa.template all_arrived<slot>();
+        opb.template all_arrived<slot>();
         k_wait();
         const int64_t ka = ka_next, kb = kb_next;
         const unsigned ld = smem_lds + S * kRingStage;
         static_for<0, NMFMA>([&](auto q_t) {
             constexpr int q = decltype(q_t)::value;
-            acc[q / TN][q % TN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, fa[slot][q / TN]),
-                                                                         __builtin_bit_cast(bf8_t, fb[slot][q % TN]),
+            acc[q / TN][q % TN] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(opa.template get<slot, q / TN>(), opb.template get<slot, q % TN>(),
                                                                          acc[q / TN][q % TN], 0, 0, 0);
-#ifdef CTC_BF16_RING_BURST_READS
-            if (q == 0) read_frags(std::integral_constant<int, slot ^ 1>(), std::integral_constant<int, SN>());
-#else
 #ifndef CTC_BF16_RING_READ_EVERY
 #define CTC_BF16_RING_READ_EVERY 2
 #endif
 #ifndef CTC_BF16_RING_DMA_FIRST
-#define CTC_BF16_RING_DMA_FIRST 1
+#define CTC_BF16_RING_DMA_FIRST 14  // behind the reads of A: DMAs among transposing reads cost up to half the rate
 #endif
             constexpr int EVERY = CTC_BF16_RING_READ_EVERY, DF = CTC_BF16_RING_DMA_FIRST;
-            if (q % EVERY == 0 && q / EVERY < TM + TN)
-                read_one(std::integral_constant<int, slot ^ 1>(), std::integral_constant<int, SN>(), std::integral_constant<int, (q / EVERY) % (TM + TN)>());
-#endif
+            if constexpr (q % EVERY == 0 && q / EVERY < TM + TN)
+                read_one(std::integral_constant<int, slot ^ 1>(), std::integral_constant<int, SN>(), std::integral_constant<int, q / EVERY>());
             if (q >= DF && q < DF + 4 * NDMA && (q - DF) % 4 == 0) issue((q - DF) / 4, ld, ka, kb);
             if (q == 29) advance();
             __builtin_amdgcn_sched_barrier(0);
@@ -761,8 +829,10 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
     // the requests past the end have landed before the epilogue takes the stages over, and the last
     // fragment reads (of a tile nobody multiplies) have returned
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    lds_wait12(fa[0], fb[0]);
-    lds_wait12(fa[1], fb[1]);
+    opa.template all_arrived<0>();
+    opa.template all_arrived<1>();
+    opb.template all_arrived<0>();
+    opb.template all_arrived<1>();
     __syncthreads();
 #ifdef CTC_CLOCK
     if (t == 0 && blockIdx.y == 0 && (blockIdx.x == 100 || blockIdx.x == 500 || blockIdx.x == 900)) {
@@ -773,13 +843,18 @@ __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams
     store_tile_bf16<BT, TM, TN>(p, acc, smem, C, m0, n0, wm0, wn0, t, lane, partial, sid, chunk);
 }
 
-// both operands K-major, the 256 tile, K a multiple of 32 with k offsets affine (step 1) inside aligned
-// groups of 32, lane offsets that fit 32 bits
+// both operands read in 16-byte vectors, the 256 tile, K a multiple of 32 with k offsets affine inside
+// aligned groups of 32 (step 1 for a K-major operand), lane offsets that fit 32 bits
 bool ring_supported(int la, int lb, int bt, const GemmParams &p)
 {
     static const bool off = getenv("CTC_TC_NO_BF16_RING") != nullptr;
-    return !off && bt == 256 && la == 0 && lb == 0 && p.k32_affine != 0 && p.ka_in == 1 && p.kb_in == 1 && p.K >= kRingBK &&
-           p.K % kRingBK == 0;
+    static const bool no_outer = getenv("CTC_TC_NO_BF16_RING_OUTER") != nullptr;
+    if (off || bt != 256 || la == kLayScalar || lb == kLayScalar || (no_outer && (la != 0 || lb != 0))) return false;
+    if (p.k32_affine == 0 || p.K < kRingBK || p.K % kRingBK != 0) return false;
+    const int64_t step_max = int64_t(1) << 22;  // 31 lines of a K-tile stay inside the 32-bit lane offset
+    if (la == 0 ? p.ka_in != 1 : (p.ka_in < 0 || p.ka_in > step_max || p.M < 8)) return false;
+    if (lb == 0 ? p.kb_in != 1 : (p.kb_in < 0 || p.kb_in > step_max || p.N < 8)) return false;
+    return true;
 }
 
 // Sums the K chunks of the split tiles in chunk order and writes C = alpha * sum + beta * C in bf16.
@@ -889,7 +964,7 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
 
 std::atomic<int64_t> g_ring_launches{0};
 
-hipError_t launch_ring(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
+template <int LA, int LB> hipError_t launch_ring(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     constexpr int BT = 256;
     g_ring_launches.fetch_add(1);
@@ -902,7 +977,7 @@ hipError_t launch_ring(const GemmParams &p, const GemmSchedule &sch, void *ws, h
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
     if (sch.nbm != (int)((p.M + BT - 1) / BT) || sch.nbn != (int)((p.N + BT - 1) / BT)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(gemm_bf16_ring_kernel, dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1), dim3(2 * BT),
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<LA, LB>), dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1), dim3(2 * BT),
                        0, stream, q);
     if (sch.tail_tiles > 0)
         hipLaunchKernelGGL(splitk_fixup_bf16_kernel<BT>, dim3((unsigned)(sch.tail_tiles * (BT / 16))), dim3(256), 0, stream, q);
@@ -967,7 +1042,14 @@ hipError_t launch_gemm_bf16(int la, int lb, int bm, const GemmParams &p, const G
 {
     if (la < 0 || la > 2 || lb < 0 || lb > 2) return hipErrorInvalidValue;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
-    if (ring_supported(la, lb, tile_edge(la, lb, bm), p)) return launch_ring(p, sch, ws, stream);
+    if (ring_supported(la, lb, tile_edge(la, lb, bm), p)) {
+        switch (la * 2 + lb) {
+        case 0: return launch_ring<0, 0>(p, sch, ws, stream);
+        case 1: return launch_ring<0, 1>(p, sch, ws, stream);
+        case 2: return launch_ring<1, 0>(p, sch, ws, stream);
+        default: return launch_ring<1, 1>(p, sch, ws, stream);
+        }
+    }
     if (tile_edge(la, lb, bm) == 256) {
         switch (la * 2 + lb) {
         case 0: return launch_one<0, 0, 256>(p, sch, ws, stream);

@@ -247,10 +247,23 @@ def test_bf16_linearity_at_size(cuda):
     assert (got - rows).abs().max() <= TOL * rows.abs().max()
 
 
-# Two K-major operands, the 256 tile and a K that is a multiple of 32 with k offsets affine inside aligned
-# groups of 32 take the ring kernel (K-tiles of 32 in four stages, LDS-DMA issued from assembly).
+# Two operands read in 16-byte vectors, the 256 tile and a K that is a multiple of 32 with k offsets affine
+# inside aligned groups of 32 take the ring kernel (K-tiles of 32 in four stages, LDS-DMA issued from
+# assembly).  An operand is K-major ("k_vec": unit stride along K) or outer-major ("outer_vec": unit stride along
+# its rows, read back through the transposing LDS loads).
 RING_CASES = [
     ("one_k_tile", "ak,bk->ab", dict(a=264, b=648, k=32)),
+    ("outer_b_one_k_tile", "ak,kb->ab", dict(a=264, b=648, k=32)),
+    ("outer_b_ragged_edges", "ak,kb->ab", dict(a=520, b=392, k=96)),
+    ("outer_b_splitk", "ak,kb->ab", dict(a=300, b=264, k=3072)),
+    ("outer_a", "ka,bk->ab", dict(a=392, b=300, k=160)),
+    ("outer_a_ragged_edges", "ka,bk->ab", dict(a=520, b=777, k=96)),
+    ("outer_both", "ka,kb->ab", dict(a=392, b=520, k=224)),
+    ("outer_both_splitk", "ka,kb->ab", dict(a=264, b=264, k=2048)),
+    ("outer_b_headline_shape", "aeim,ebmj->abij", dict(a=12, b=10, e=3, i=24, j=32, m=32)),
+    ("outer_b_two_contracted_modes", "aef,efb->ab", dict(a=392, b=264, e=3, f=64)),
+    ("outer_both_batched", "zka,zkb->zab", dict(z=3, a=264, b=328, k=64)),
+    ("outer_b_permuted_result", "ak,kb->ba", dict(a=264, b=328, k=64)),
     ("three_k_tiles_ragged_edges", "ak,bk->ab", dict(a=520, b=392, k=96)),
     ("seven_k_tiles", "ak,bk->ab", dict(a=300, b=777, k=224)),
     ("splitk", "ak,bk->ab", dict(a=300, b=264, k=3072)),
@@ -269,7 +282,9 @@ def test_bf16_ring_kernel(cuda, oracle, monkeypatch, name, spec, ext):
     B = oracle.fill(nb, 0xC7C0B, BF16)
     plan = ctc_amd.Plan(spec, ext, "bf16")
     s = plan.summary()
-    assert tuple(s["tile"]) == (256, 256, 64) and (s["layout_a"], s["layout_b"]) == ("k_vec", "k_vec"), s
+    assert tuple(s["tile"]) == (256, 256, 64) and "scalar" not in (s["layout_a"], s["layout_b"]), s
+    if name.startswith("outer_"):
+        assert "outer_vec" in (s["layout_a"], s["layout_b"]), s
     dC = torch.full((nc,), float("nan"), dtype=torch.bfloat16, device=cuda)
     before = ctc_amd.get_option("launches_bf16_ring")
     plan.execute(_to_dev(A, cuda), _to_dev(B, cuda), dC)
@@ -285,7 +300,8 @@ def test_bf16_ring_kernel(cuda, oracle, monkeypatch, name, spec, ext):
 def test_bf16_ring_kernel_is_left_alone_when_it_does_not_apply(cuda, oracle, monkeypatch):
     monkeypatch.setenv("CTC_TC_FORCE_TILE", "256")
     for spec, ext in (("ak,bk->ab", dict(a=264, b=264, k=72)),      # K no multiple of 32
-                      ("ak,kb->ab", dict(a=264, b=264, k=64)),      # an outer-major operand
+                      ("ak,kb->ab", dict(a=264, b=262, k=64)),      # an operand without 16-byte vectors
+                      ("aeim,ebmj->abij", dict(a=12, b=12, e=4, i=24, j=24, m=24)),  # groups of 32 straddle m
                       ("aef,ebf->ab", dict(a=264, b=264, e=4, f=24))):  # groups of 32 straddle a mode of B
         na, nb, nc = _sizes(spec, ext)
         A = oracle.fill(na, 0xC7C0A, BF16)
