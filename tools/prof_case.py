@@ -1,6 +1,6 @@
 """Runs one contraction a few times so that rocprofv3 can attach counters to its kernel.
 
-  python tools/prof_case.py six|ccsd96|ccsd64|ccsd96_f32|ccsd64_bf16|nt8k_bf16|nn8k_bf16|tn8k_bf16|tt8k_bf16 [iters]
+  python tools/prof_case.py six|ccsd96|ccsd64|ccsd96_f32|ccsd96_bf16|ccsd64_bf16|nt8k_bf16|nn8k_bf16|tn8k_bf16|tt8k_bf16 [iters]
 """
 import os
 import sys
@@ -15,6 +15,7 @@ CASES = {
     "ccsd96": ("aeim,ebmj->abij", dict(a=96, b=96, i=96, j=96, e=96, m=96), "f64"),
     "ccsd64": ("aeim,ebmj->abij", dict(a=64, b=64, i=64, j=64, e=64, m=64), "f64"),
     "ccsd96_f32": ("aeim,ebmj->abij", dict(a=96, b=96, i=96, j=96, e=96, m=96), "f32"),
+    "ccsd96_bf16": ("aeim,ebmj->abij", dict(a=96, b=96, i=96, j=96, e=96, m=96), "bf16"),
     "ccsd64_bf16": ("aeim,ebmj->abij", dict(a=64, b=64, i=64, j=64, e=64, m=64), "bf16"),
     "nt8k_bf16": ("ak,bk->ab", dict(a=8192, b=8192, k=8192), "bf16"),
     "nn8k_bf16": ("ak,kb->ab", dict(a=8192, b=8192, k=8192), "bf16"),
