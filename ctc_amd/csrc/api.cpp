@@ -276,6 +276,7 @@ size_t worst_splitk_bytes(const ctc::Plan &p)
     g.k32_affine = (g.k16_affine && p.k32_affine) ? 1 : 0;
     g.ka_in = p.ka_in;
     g.kb_in = p.kb_in;
+    g.k_run = plan_dma_ok(p) ? p.k_run : 0;
     size_t worst = 0;
     for (int va = 0; va < 2; ++va)
         for (int vb = 0; vb < 2; ++vb) {
@@ -351,6 +352,7 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     g.k32_affine = (g.k16_affine && p.k32_affine) ? 1 : 0;
     g.ka_in = p.ka_in;
     g.kb_in = p.kb_in;
+    g.k_run = plan_dma_ok(p) ? p.k_run : 0;
 
     // vector loads need 16-byte aligned bases; otherwise fall back to element loads
     int la = p.layout_a, lb = p.layout_b;

@@ -19,8 +19,10 @@
 //     or four (fp32) address registers per operand.
 // Needs: both operands in a 16-byte-vector layout, K a multiple of the K-tile, k offsets that are affine
 // inside every aligned group of that many (GemmParams::k8_affine / k16_affine; e.g. every contracted mode's
-// extent a multiple of it, or one contracted mode), row / column offsets below 2^28 elements.  Everything
-// else takes gemm_kernels.hip.
+// extent a multiple of it, or one contracted mode), row / column offsets below 2^28 elements.  Runs of affine
+// k offsets that are no multiple of the K-tile (GemmParams::k_run) are served by ragged K-tiles: the last
+// tile of a run is the run's last K-tile-many elements, and the elements it shares with its predecessor are
+// zeroed in the fragments.  Everything else takes gemm_kernels.hip.
 // Tile order, split of the last round along K, epilogue: as there.  A launch may carry fewer workgroups
 // than items (fp64 with many rounds: one per slot); a workgroup then walks items b, b + gridDim.x, ...
 #include "gemm_device.hpp"
@@ -153,10 +155,11 @@ template <typename T, int LAY, int RB> struct Operand {
 // NSUB: images per operand and stage.  2 (with RB = 32) puts two K-tiles of 32-byte rows, each with its own k
 // offset, into one stage: the K loop then has the shape of the 64-byte geometry (one barrier per 32 MFMAs per
 // wave) for k tables that are affine in groups of half a K-tile only.
-template <typename T, int LA, int LB, int RB, int NSUB>
+template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED>
 __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
 {
     static_assert(NSUB == 1 || (NSUB == 2 && RB == 32), "two sub-tiles only with 32-byte rows");
+    static_assert(!RAGGED || (NSUB == 1 && RB == 64), "ragged K-tiles exist for the 64-byte geometry");
     constexpr int BM = kBM, BN = kBN, BKS = tile_k<T, RB>(), BK = NSUB * BKS, WN = 2;
     constexpr int kOpBytes = op_bytes<RB>(), kOperandBytes = NSUB * kOpBytes, kStageBytes = 2 * kOperandBytes;
     constexpr int TM = 4, TN = 4, NMFMA = TM * TN, KSTEPS = BK / 4, KS1 = BKS / 4;  // k-steps per stage / per image
@@ -215,10 +218,22 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     const char *B = reinterpret_cast<const char *>(static_cast<const T *>(p.B) + p.bat_b[bz]);
     T *C = static_cast<T *>(p.C) + p.bat_c[bz];
 
-    const int nk_total = (int)(p.K / BK);
+    // RAGGED: the k tables are affine inside runs of p.k_run >= BK contracted elements only, and a run is no
+    // multiple of the K-tile.  A run is then cut into ceil(run / BK) tiles whose last one is the LAST BK elements
+    // of the run: it overlaps its predecessor by `skip_tail` elements, which are zeroed in the fragments of both
+    // operands (in registers, behind the wait that delivers them; k-steps that are overlap entirely are not
+    // multiplied at all), so every tile is one affine window of BK elements inside the operands.
+    const int run = RAGGED ? (int)p.k_run : BK;
+    const int tiles_per_run = (run + BK - 1) / BK;
+    const int skip_tail = tiles_per_run * BK - run;
+    const int nk_total = RAGGED ? (int)(p.K / run) * tiles_per_run : (int)(p.K / BK);
     const int kt_first = partial ? (int)((int64_t)chunk * nk_total / p.split) : 0;
     const int kt_last = partial ? (int)((int64_t)(chunk + 1) * nk_total / p.split) : nk_total;
     const int nk = kt_last - kt_first;
+    // RAGGED: run and tile inside the run of the chunk's first tile, of the tile requested next, and the tile
+    // inside its run of the tile multiplied next
+    const int run_first = RAGGED ? kt_first / tiles_per_run : 0, tile_first = RAGGED ? kt_first % tiles_per_run : 0;
+    int rq_run = run_first, rq_tile = tile_first, mm_tile = tile_first;
 
     // everything that goes through ordinary loads and LDS stores comes first: once a DMA is in flight the
     // compiler drains it in front of every LDS access it can see
@@ -254,7 +269,8 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     auto k_fetch = [&]() {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
-            const int64_t *pa = p.k_a + (int64_t)(kt_first + tl) * BK + sub * BKS, *pb = p.k_b + (int64_t)(kt_first + tl) * BK + sub * BKS;
+            const int64_t k0 = RAGGED ? (int64_t)rq_run * run + min(rq_tile * BK, run - BK) : (int64_t)(kt_first + tl) * BK + sub * BKS;
+            const int64_t *pa = p.k_a + k0, *pb = p.k_b + k0;
             asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(ka_next[sub]) : "s"(pa));
             asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(kb_next[sub]) : "s"(pb));
         }
@@ -265,6 +281,15 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     };
     auto advance = [&]() {
         tl = (tl + 1 == nk) ? 0 : tl + 1;
+        if (RAGGED) {
+            if (tl == 0) {
+                rq_run = run_first;
+                rq_tile = tile_first;
+            } else if (++rq_tile == tiles_per_run) {
+                rq_tile = 0;
+                ++rq_run;
+            }
+        }
         k_fetch();
     };
     k_fetch();
@@ -322,6 +347,9 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
         constexpr int S = decltype(stage_t)::value, SN = (S + 1) % kStages, SL = (S + kStages - 1) % kStages;
         const unsigned ld = smem_lds + SL * kStageBytes;
         int64_t ka[NSUB], kb[NSUB];
+        // RAGGED: leading elements of this tile that its predecessor has multiplied already
+        const int skip = (RAGGED && mm_tile == tiles_per_run - 1) ? skip_tail : 0;
+        if (RAGGED) mm_tile = (mm_tile + 1 == tiles_per_run) ? 0 : mm_tile + 1;
         static_for<0, KSTEPS>([&](auto kk_t) {
             // with one k-step per K-tile the fragment slots alternate per tile (the stages' parity)
             constexpr int kk = decltype(kk_t)::value, slot = (KSTEPS == 1 ? S : kk) & 1;
@@ -344,9 +372,24 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
                     kb[sub] = kb_next[sub];
                 }
             }
+            // RAGGED: lane group fk holds element 4 kk + fk of the tile.  A k-step whose elements are overlap
+            // entirely (never the last one of a tile) is not multiplied: its MFMAs sit behind wave-uniform
+            // branches, everything that is dealt out between them (each asynchronous read and DMA exists once
+            // in the code) runs as always.  A k-step that is overlap in part has those elements zeroed.
+            // (Only with more than two k-steps per tile: the launch rule below sends no run whose last tile is
+            // overlap by half or more to this kernel, so with two k-steps none is ever idle, and the branches
+            // would cost the fp64 kernel 3 %.)
+            const bool idle = RAGGED && KSTEPS > 2 && !last && skip >= 4 * kk + 4;
+            if (RAGGED && skip > 4 * kk && !idle) {
+                const bool dead = 4 * kk + fk < skip;
+#pragma unroll
+                for (int b = 0; b < TM; ++b) fa[slot][b] = dead ? T(0) : fa[slot][b];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) fb[slot][b] = dead ? T(0) : fb[slot][b];
+            }
             static_for<0, NMFMA>([&](auto q_t) {
                 constexpr int q = decltype(q_t)::value;
-                acc[q / TN][q % TN] = Tr::mfma(fa[slot][q / TN], fb[slot][q % TN], acc[q / TN][q % TN]);
+                if (!idle) acc[q / TN][q % TN] = Tr::mfma(fa[slot][q / TN], fb[slot][q % TN], acc[q / TN][q % TN]);
                 if (q == 0) {
                     if (last) read_frags(std::integral_constant<int, slot ^ 1>(), I0(), std::integral_constant<int, SN>());
                     else read_frags(std::integral_constant<int, slot ^ 1>(), std::integral_constant<int, (kk + 1) % KSTEPS>(), stage_t);
@@ -387,7 +430,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
 #endif
 }
 
-template <typename T, int LA, int LB, int RB, int NSUB> int resident_slots()
+template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> int resident_slots()
 {
     static std::atomic<int> cache[64];  // 0: not queried yet; host threads of several devices may race here
     int dev = 0;
@@ -395,7 +438,7 @@ template <typename T, int LA, int LB, int RB, int NSUB> int resident_slots()
     if (cache[dev].load() == 0) {
         int cus = 0, per_cu = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<T, LA, LB, RB, NSUB>, 256, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<T, LA, LB, RB, NSUB, RAGGED>, 256, 0) != hipSuccess) return 0;
         cache[dev].store(cus * per_cu > 0 ? cus * per_cu : -1);
     }
     const int slots = cache[dev].load();
@@ -423,7 +466,7 @@ int best_split(int64_t tail, int slots, int nk, int min_chunk_tiles)
     return best_f;
 }
 
-template <typename T, int LA, int LB, int RB, int NSUB> hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
+template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
 {
     constexpr int BK = NSUB * tile_k<T, RB>();
     GemmSchedule s;
@@ -436,8 +479,8 @@ template <typename T, int LA, int LB, int RB, int NSUB> hipError_t schedule_one(
     s.tail_tiles = 0;
     s.ws_bytes = 0;
     static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
-    const int slots = resident_slots<T, LA, LB, RB, NSUB>();
-    const int nk = (int)(p.K / BK);
+    const int slots = resident_slots<T, LA, LB, RB, NSUB, RAGGED>();
+    const int nk = RAGGED ? (int)((p.K / p.k_run) * ((p.k_run + BK - 1) / BK)) : (int)(p.K / BK);
     if (!no_split && slots > 0 && p.batch == 1) {
         const int tail = (int)(tiles % slots);
         if (tail > 0) {
@@ -454,7 +497,7 @@ template <typename T, int LA, int LB, int RB, int NSUB> hipError_t schedule_one(
     return hipSuccess;
 }
 
-template <typename T, int LA, int LB, int RB, int NSUB>
+template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED>
 hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     GemmParams q = p;
@@ -473,11 +516,11 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     // CTC_TC_DMA_PERSIST=0 / 1: never / whenever there are more items than slots.
     static const int persist = getenv("CTC_TC_DMA_PERSIST") ? atoi(getenv("CTC_TC_DMA_PERSIST")) : -1;
     if (persist != 0) {
-        const unsigned slots = (unsigned)resident_slots<T, LA, LB, RB, NSUB>();
+        const unsigned slots = (unsigned)resident_slots<T, LA, LB, RB, NSUB, RAGGED>();
         if (slots >= 8 && slots % 8 == 0 && items > slots && (persist == 1 || (sizeof(T) == 8 && items >= 4 * slots))) items = slots;
     }
     dim3 grid(items, (unsigned)p.batch, 1);
-    hipLaunchKernelGGL((gemm_dma_kernel<T, LA, LB, RB, NSUB>), grid, dim3(256), 0, stream, q);
+    hipLaunchKernelGGL((gemm_dma_kernel<T, LA, LB, RB, NSUB, RAGGED>), grid, dim3(256), 0, stream, q);
     if (sch.tail_tiles > 0) {
         hipError_t e = launch_splitk_fixup_128(sizeof(T) == 8 ? 0 : 1, q, sch.tail_tiles, stream);
         if (e != hipSuccess) return e;
@@ -485,12 +528,12 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     return hipGetLastError();
 }
 
-template <typename T, int RB, int NSUB>
+template <typename T, int RB, int NSUB, bool RAGGED>
 hipError_t dispatch(int layout_a, int layout_b, const GemmParams &p, GemmSchedule *sch_out, const GemmSchedule *sch_in,
                     void *ws, hipStream_t stream)
 {
 #define CTC_CASE(A_, B_) \
-    case A_ * 2 + B_: return sch_out ? schedule_one<T, A_, B_, RB, NSUB>(p, sch_out) : launch_one<T, A_, B_, RB, NSUB>(p, *sch_in, ws, stream);
+    case A_ * 2 + B_: return sch_out ? schedule_one<T, A_, B_, RB, NSUB, RAGGED>(p, sch_out) : launch_one<T, A_, B_, RB, NSUB, RAGGED>(p, *sch_in, ws, stream);
     switch (layout_a * 2 + layout_b) {
         CTC_CASE(0, 0) CTC_CASE(0, 1) CTC_CASE(1, 0) CTC_CASE(1, 1)
     default: return hipErrorInvalidValue;
@@ -500,7 +543,7 @@ hipError_t dispatch(int layout_a, int layout_b, const GemmParams &p, GemmSchedul
 
 // The geometry the launch takes: 0 none (it does not qualify), 1: 64-byte rows, 2: two images of 32-byte rows
 // per stage (k tables affine in groups of half a K-tile), 3: one image of 32-byte rows (K a multiple of half
-// a K-tile only)
+// a K-tile only), 4: 64-byte rows with ragged K-tiles (k tables affine in runs that are no multiple of a K-tile)
 int dma_gemm_geometry(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
 {
     static const bool off = getenv("CTC_TC_NO_DMA_GEMM") != nullptr;
@@ -517,12 +560,27 @@ int dma_gemm_geometry(int dtype, int layout_a, int layout_b, int bm, int bn, con
     const int bk = dtype == 0 ? 8 : 16;  // K-tile of the 64-byte geometry
     const bool full = dtype == 0 ? p.k8_affine != 0 : p.k16_affine != 0;
     const bool half = dtype == 0 ? p.k4_affine != 0 : p.k8_affine != 0;
-    if (full && p.K >= bk && p.K % bk == 0) return 1;
+    static const bool force_ragged = getenv("CTC_TC_DMA_FORCE_RAGGED") != nullptr;  // A/B runs of the ragged bookkeeping
+    if (full && p.K >= bk && p.K % bk == 0 && !(force_ragged && p.k_run >= bk)) return 1;
+    // Ragged K-tiles of the 64-byte geometry: runs of k_run affine elements cut into ceil(k_run / bk) tiles,
+    // the last one overlapping its predecessor.  Taken when no geometry with exact tiles applies.
+    static const bool no_ragged = getenv("CTC_TC_NO_DMA_RAGGED") != nullptr;
+    bool ragged = false;
+    if (!no_ragged && p.k_run >= bk && p.k_run <= 0x7FFFFFFF && p.K % p.k_run == 0 && p.K / p.k_run * ((p.k_run + bk - 1) / bk) <= 0x3FFFFFFF) {
+        // the last tile of a run must be live by more than half: measured against the register-staged kernel,
+        // fp64 extents 62 .. 94 with 6 live elements of 8 gain 1 - 2.5 %, with 2 of 8 they lose up to 2.4 %;
+        // fp32 with 12 of 16 gains 4 - 6 %, with 4 of 16 0 - 3 %
+        const int64_t live = p.k_run - (p.k_run - 1) / bk * bk;
+        ragged = 2 * live > bk;
+    }
+    if (ragged && force_ragged) return 4;
     if (half && p.K >= bk && p.K % bk == 0) return 2;
     // One image of 32-byte rows has a barrier per sixteen MFMAs per wave: it beats the register-staged kernel
     // on problems of two rounds of tiles and more and loses below (fp32, 625 tiles mostly cut along K: 118 -> 110).
     const int64_t tiles = ((p.M + kBM - 1) / kBM) * ((p.N + kBN - 1) / kBN);
-    return (half && p.K >= bk / 2 && p.K % (bk / 2) == 0 && tiles * p.batch >= 1024) ? 3 : 0;
+    if (half && p.K >= bk / 2 && p.K % (bk / 2) == 0 && tiles * p.batch >= 1024) return 3;
+    if (ragged) return 4;
+    return 0;
 }
 
 template <typename T>
@@ -530,9 +588,10 @@ hipError_t dispatch_geometry(int g, int la, int lb, const GemmParams &p, GemmSch
                              hipStream_t stream)
 {
     switch (g) {
-    case 1: return dispatch<T, 64, 1>(la, lb, p, sch_out, sch_in, ws, stream);
-    case 2: return dispatch<T, 32, 2>(la, lb, p, sch_out, sch_in, ws, stream);
-    case 3: return dispatch<T, 32, 1>(la, lb, p, sch_out, sch_in, ws, stream);
+    case 1: return dispatch<T, 64, 1, false>(la, lb, p, sch_out, sch_in, ws, stream);
+    case 2: return dispatch<T, 32, 2, false>(la, lb, p, sch_out, sch_in, ws, stream);
+    case 3: return dispatch<T, 32, 1, false>(la, lb, p, sch_out, sch_in, ws, stream);
+    case 4: return dispatch<T, 64, 1, true>(la, lb, p, sch_out, sch_in, ws, stream);
     default: return hipErrorInvalidValue;
     }
 }

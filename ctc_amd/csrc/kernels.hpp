@@ -42,6 +42,9 @@ struct GemmParams {
     // k4_affine, k16_affine, k32_affine: the same for groups of 4 / 16 / 32
     int k4_affine = 0, k8_affine = 0, k16_affine = 0, k32_affine = 0;
     int64_t ka_in = 0, kb_in = 0;
+    // k_run > 0: K is a multiple of k_run and the tables are affine (same steps) inside every aligned run of
+    // that many k (runs of the fastest contracted mode)
+    int64_t k_run = 0;
 };
 
 struct GemmSchedule {

@@ -336,6 +336,10 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
         p.k16_affine = affine_groups(p.k_a, p.K, 16, p.ka_in) && affine_groups(p.k_b, p.K, 16, p.kb_in);
         p.k8_affine = affine_groups(p.k_a, p.K, 8, p.ka_in) && affine_groups(p.k_b, p.K, 8, p.kb_in);
         p.k4_affine = affine_groups(p.k_a, p.K, 4, p.ka_in) && affine_groups(p.k_b, p.K, 4, p.kb_in);
+        const int64_t run = p.ex_k.empty() ? 0 : p.modes[p.ex_k[0]].extent;
+        if (run >= 2 && run <= 0x7FFFFFFF && p.K % run == 0 && affine_groups(p.k_a, p.K, (int)run, p.ka_in) &&
+            affine_groups(p.k_b, p.K, (int)run, p.kb_in))
+            p.k_run = run;
     }
     build_table(p, p.ex_n, gb, p.N, p.col_b);
     for (int64_t v : p.row_a) p.max_row_a = v > p.max_row_a ? v : p.max_row_a;

@@ -65,6 +65,9 @@ struct Plan {
     // of 8): a kernel that walks K in tiles of 8 needs one table entry per tile
     bool k4_affine = false, k8_affine = false, k16_affine = false, k32_affine = false;  // groups of 4 / 8 / 16 / 32
     int64_t ka_in = 0, kb_in = 0;
+    // length of the runs of k inside which both k tables are affine with those steps (the extent of the
+    // fastest contracted mode; K is a multiple of it); 0: none
+    int64_t k_run = 0;
     // largest row offset of A / column offset of B (elements)
     int64_t max_row_a = 0, max_col_b = 0;
 

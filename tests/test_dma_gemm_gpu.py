@@ -75,6 +75,17 @@ CASES = [
     ("k4x2_outer_operands", "efa,feb->ab", dict(a=2600, b=2500, e=6, f=12)),
     ("k4x2_split_k_tail", "aef,feb->ab", dict(a=1024, b=1152, e=340, f=12)),
     ("k4_split_k_tail", "ak,kb->ab", dict(a=4224, b=4480, k=1036)),
+    # k tables affine in runs that are no multiple of 4: ragged K-tiles of 8 (the last tile of a run overlaps
+    # its predecessor; the overlap is zeroed in the fragments)
+    ("ragged_nn_kmajor_outer", "ak,kb->ab", dict(a=2500, b=2600, k=62)),
+    ("ragged_nt_kmajor_kmajor", "ak,bk->ab", dict(a=2562, b=2430, k=30)),
+    ("ragged_tn_outer_outer", "ka,kb->ab", dict(a=2600, b=2498, k=22)),
+    ("ragged_tt_outer_kmajor", "ka,bk->ab", dict(a=2434, b=2690, k=14)),
+    ("ragged_ccsd_three_by_22", "aeim,ebmj->abij", dict(a=52, b=50, i=50, j=52, e=3, m=22)),
+    ("ragged_ccsd_other_layouts", "eaim,jbem->abij", dict(a=48, b=50, i=54, j=52, e=5, m=14)),
+    ("ragged_split_k_tail", "aef,feb->ab", dict(a=1024, b=1152, e=150, f=22)),
+    ("ragged_split_k_everything", "ka,bk->ab", dict(a=256, b=384, k=32774)),
+    ("ragged_batched", "zak,zkb->zab", dict(z=3, a=1500, b=1400, k=38)),
 ]
 
 
@@ -102,6 +113,12 @@ F32_CASES = [
     ("split_k_everything", "ka,bk->ab", dict(a=256, b=384, k=32768)),
     ("batched", "zak,zkb->zab", dict(z=3, a=1500, b=1400, k=32)),
     ("rank6", "adij,bcdk->abcijk", dict(a=6, b=20, c=20, i=20, j=24, k=8, d=32)),
+    # ragged K-tiles of 16
+    ("ragged_nn_kmajor_outer", "ak,kb->ab", dict(a=2500, b=2600, k=28)),
+    ("ragged_tt_outer_kmajor", "ka,bk->ab", dict(a=2436, b=2692, k=44)),
+    ("ragged_nt_kmajor_kmajor", "ak,bk->ab", dict(a=2564, b=2432, k=60)),
+    ("ragged_ccsd_three_by_28", "aeim,ebmj->abij", dict(a=52, b=50, i=50, j=52, e=3, m=28)),
+    ("ragged_split_k_tail", "ka,kb->ab", dict(a=1024, b=1152, k=4092)),
 ]
 ALL_CASES = [c + ("f64",) for c in CASES] + [c + ("f32",) for c in F32_CASES]
 
@@ -143,9 +160,12 @@ def test_which_launches_take_the_dma_kernel(cuda):
     big = dict(a=4096, b=4096)
     assert _delta(run("ak,kb->ab", dict(big, k=256))) == (0, 1, 0, 0)
     assert _delta(run("ak,kb->ab", dict(big, k=260))) == (0, 1, 0, 0)                 # K a multiple of 4: K-tiles of 4
-    assert _delta(run("ak,kb->ab", dict(big, k=262))) == (1, 0, 0, 0)                 # K not a multiple of 4
+    assert _delta(run("ak,kb->ab", dict(big, k=262))) == (0, 1, 0, 0)                 # K not a multiple of 4: ragged K-tiles of 8
+    assert _delta(run("ak,kb->ab", dict(big, k=263))) == (1, 0, 0, 0)                 # odd K: no 16-byte vectors in A
     assert _delta(run("aef,feb->ab", dict(big, e=4, f=12))) == (0, 1, 0, 0)            # groups of 8 straddle a mode, of 4 do not
-    assert _delta(run("aef,feb->ab", dict(big, e=4, f=10))) == (1, 0, 0, 0)            # groups of 4 straddle a mode
+    assert _delta(run("aef,feb->ab", dict(big, e=4, f=10))) == (1, 0, 0, 0)            # groups of 4 straddle a mode; the last K-tile of a run of 10 would be 2 live elements of 8
+    assert _delta(run("aef,feb->ab", dict(big, e=4, f=14))) == (0, 1, 0, 0)            # runs of 14: ragged K-tiles, 6 live elements of 8 in a run's last one
+    assert _delta(run("aef,feb->ab", dict(big, e=40, f=6))) == (1, 0, 0, 0)            # runs shorter than a K-tile
     assert _delta(run("aef,feb->ab", dict(big, e=16, f=8))) == (0, 1, 0, 0)            # they do not
     assert _delta(run("ak,kb->ab", dict(a=512, b=512, k=256))) == (1, 0, 0, 0)         # small tile
     assert _delta(run("ak,kb->ab", dict(big, k=256), x[1:])) == (1, 0, 0, 0)           # unaligned base: element loads
@@ -153,7 +173,8 @@ def test_which_launches_take_the_dma_kernel(cuda):
     c32 = torch.zeros(4096 * 4096, dtype=torch.float32, device=cuda)
     assert _delta(lambda: ctc_amd.Plan("ak,kb->ab", dict(big, k=256), "f32").execute(f32, f32, c32)) == (0, 1, 0, 0)
     assert _delta(lambda: ctc_amd.Plan("ak,kb->ab", dict(big, k=248), "f32").execute(f32, f32, c32)) == (0, 1, 0, 0)  # K-tiles of 8
-    assert _delta(lambda: ctc_amd.Plan("ak,kb->ab", dict(big, k=252), "f32").execute(f32, f32, c32)) == (1, 0, 0, 0)
+    assert _delta(lambda: ctc_amd.Plan("ak,kb->ab", dict(big, k=252), "f32").execute(f32, f32, c32)) == (0, 1, 0, 0)  # ragged K-tiles of 16
+    assert _delta(lambda: ctc_amd.Plan("ak,kb->ab", dict(big, k=250), "f32").execute(f32, f32, c32)) == (1, 0, 0, 0)  # no 16-byte vectors in A
     ctc_amd.set_option("dma_gemm", 0)
     try:
         assert _delta(run("ak,kb->ab", dict(big, k=256))) == (1, 0, 0, 0)
