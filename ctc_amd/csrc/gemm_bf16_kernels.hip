@@ -485,12 +485,21 @@ __global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(co
         unsigned char *na = smem + (buf ^ 1) * 2 * kImageBytes;
         const bool more = kt + 1 < nk;
         const int64_t k_next = (int64_t)(kt + 1) * BK;
-        if (more) {
-            // the other buffer was last read before the barrier that ended the previous tile
-            stage_begin(sa, A, p.k_a, k_next, na);
-            stage_begin(sb, B, p.k_b, k_next, na + kImageBytes);
-            prefetch(kt + 2);
-        }
+        // Where the next tile's DMAs are issued.  A global_load_lds queued in front of a ds_read_b64_tr_b16 delays
+        // it (8192^3 on the 256 tile, A K-major / B outer: 1009 -> 1155 TFLOP/s with the DMAs behind the up-front
+        // reads; A outer: 955 -> 1035 with the DMAs behind the rolling reads of A as well), while the K-major
+        // reads are indifferent and an earlier DMA has more time to land (both K-major: 1141 at once, 1109
+        // behind the up-front reads, 1036 behind the first k-step).
+        constexpr int kDmaAt = SA::OUTER ? 2 : (SB::OUTER ? 1 : 0);
+        auto begin_next = [&]() {
+            if (more) {
+                // the other buffer was last read before the barrier that ended the previous tile
+                stage_begin(sa, A, p.k_a, k_next, na);
+                stage_begin(sb, B, p.k_b, k_next, na + kImageBytes);
+                prefetch(kt + 2);
+            }
+        };
+        if (kDmaAt == 0) begin_next();
         // Both k-steps' fragments are requested up front, in k-step order, so that the second
         // half of the reads lands while the first sixteen MFMAs run; the order is pinned, the
         // compiler only adds the counted waits.
@@ -512,6 +521,7 @@ __global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(co
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[1][j] = fragment<SB::OUTER, BT>(ib, wn0 + 16 * j, 1, lane_it);
             __builtin_amdgcn_sched_barrier(0);
+            if (kDmaAt == 1) begin_next();
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -520,6 +530,7 @@ __global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(co
                 fa[i] = fragment<SA::OUTER, BT>(ia, wm0 + 16 * i, 1, lane_it);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (kDmaAt == 2) begin_next();
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -536,6 +547,7 @@ __global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(co
             for (int j = 0; j < TN; ++j) fb[ks][j] = fragment<SB::OUTER, BT>(ib, wn0 + 16 * j, ks, lane);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (kDmaAt != 0) begin_next();  // the 128 tile reads every fragment up front
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll

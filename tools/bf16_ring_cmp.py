@@ -12,7 +12,7 @@ import ctc_amd  # noqa: E402
 
 dev = torch.device("cuda:0")
 cases = [(s, dict(a=n, b=n, k=n)) for n in (8192, 4096) for s in ("ak,bk->ab", "ak,kb->ab", "ka,bk->ab", "ka,kb->ab")]
-cases += [("aeim,ebmj->abij", {m: n for m in "abeijm"}) for n in (64, 96)]
+cases += [("aeim,ebmj->abij", {m: n for m in "abeijm"}) for n in (64, 72, 80, 88, 96)]
 for spec, ext in cases:
     plan = ctc_amd.Plan(spec, ext, "bf16")
     s = plan.summary()
