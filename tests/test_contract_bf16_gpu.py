@@ -311,3 +311,43 @@ def test_bf16_ring_kernel_is_left_alone_when_it_does_not_apply(cuda, oracle, mon
         ctc_amd.Plan(spec, ext, "bf16").execute(_to_dev(A, cuda), _to_dev(B, cuda), dC)
         assert ctc_amd.get_option("launches_bf16_ring") == before, spec
         _check(oracle, _to_host(dC), oracle.contract(spec, ext, A, B, dtype=BF16))
+
+
+def test_bf16_ring_kernel_seeded_random(cuda, oracle, monkeypatch):
+    """Random operand layouts (K-major / outer-major each), ragged tile edges, one to three contracted modes,
+    alpha and beta on the 256 tile: the launches that qualify for the ring kernel must take it, and every
+    result must match the oracle."""
+    import os
+    import random
+    monkeypatch.setenv("CTC_TC_FORCE_TILE", "256")
+    rng = random.Random(0xBF16)
+    took = 0
+    n_cases = int(os.environ.get("CTC_BF16_RING_FUZZ_CASES", "24"))
+    for n in range(n_cases):
+        ext = dict(a=8 * rng.randint(30, 70), b=8 * rng.randint(30, 70), k=32 * rng.randint(1, 6))
+        ka, kb = ["k"], ["k"]
+        if rng.random() < 0.5:  # a second contracted mode, slower than k in both operands
+            ext["e"] = rng.randint(2, 3)
+            ka, kb = ["e", "k"], ["e", "k"]
+        a_modes = ["a"] + ka if rng.random() < 0.5 else ka + ["a"]
+        b_modes = ["b"] + kb if rng.random() < 0.5 else kb + ["b"]
+        c_modes = rng.choice(["ab", "ba"])
+        spec = "%s,%s->%s" % ("".join(a_modes), "".join(b_modes), c_modes)
+        alpha, beta = rng.choice([1.0, -0.5, 2.0]), rng.choice([0.0, 0.0, 1.0, -1.5])
+        na, nb, nc = _sizes(spec, ext)
+        A = oracle.fill(na, 100 + n, BF16)
+        B = oracle.fill(nb, 200 + n, BF16)
+        C0 = oracle.fill(nc, 300 + n, BF16)
+        plan = ctc_amd.Plan(spec, ext, "bf16")
+        s = plan.summary()
+        assert tuple(s["tile"]) == (256, 256, 64), (spec, ext, s)
+        dC = _to_dev(C0, cuda)
+        before = ctc_amd.get_option("launches_bf16_ring")
+        plan.execute(_to_dev(A, cuda), _to_dev(B, cuda), dC, alpha=alpha, beta=beta)
+        took += ctc_amd.get_option("launches_bf16_ring") - before
+        want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=alpha, beta=beta, dtype=BF16)
+        try:
+            _check(oracle, _to_host(dC), want)
+        except AssertionError as e:
+            raise AssertionError("%s %s alpha %g beta %g layouts %s %s: %s" % (spec, ext, alpha, beta, s["layout_a"], s["layout_b"], e))
+    assert took == n_cases, (took, n_cases)

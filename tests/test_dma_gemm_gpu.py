@@ -225,7 +225,7 @@ def test_seeded_random_contractions_on_large_tiles(cuda, oracle):
         dtype = rng.choice(["f64", "f64", "f32"])
         ext = dict(a=rng.choice([56, 60, 66]), i=rng.choice([48, 56, 64]),
                    b=rng.choice([56, 60, 66]), j=rng.choice([48, 56, 64]),
-                   e=rng.choice([1, 2, 3, 5]), m=rng.choice([8, 16, 16, 24, 32, 40, 50]))
+                   e=rng.choice([1, 2, 3, 5]), m=rng.choice([8, 16, 16, 24, 32, 40, 50, 14, 22, 28, 30, 44, 46]))
         la, lb, lc = list("aeim"), list("ebmj"), list("abij")
         for m in (la, lb, lc):
             rng.shuffle(m)
