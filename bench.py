@@ -388,7 +388,7 @@ def main():
     if rank == 0:
         s = plan.summary()
         # which tiled-GEMM kernel the timed launches took (the library counts them)
-        s["kernel_name"] = ("gemm_dma_kernel<double, %d, %d, 64, 1>" % (s["layout_a"] != "k_vec", s["layout_b"] != "k_vec")
+        s["kernel_name"] = ("gemm_dma_kernel<double, %d, %d, 64, 1, false>" % (s["layout_a"] != "k_vec", s["layout_b"] != "k_vec")
                             if ctc_amd.get_option("launches_dma_gemm") > launches_dma_before else "gemm_kernel<double>")
         achieved = flops_rank / (kernel_ms * 1e-3) * 1e-12
         out = {
