@@ -619,9 +619,15 @@ template <typename V> __device__ __forceinline__ void arrived(V &v) { asm volati
 // off[j]: byte offset of this lane's 16 bytes from the K-tile's base, wave instruction j of two (instruction
 // 2 wave + j fills bytes [(2 wave + j) KB, + 1 KB) of the image); rows past the extent repeat rows inside it
 // (their products are never stored).
-template <int LAY, int NB> struct RingOperand;
+// KG: the k table is affine inside aligned groups of KG contracted elements: 32 (the whole K-tile: one table entry
+// per tile) or 16 (one entry per half of the tile; waves 0 - 3 fetch the first half of both operands, waves 4 - 7
+// the second, so a wave still needs one entry per operand).  A K-major operand then keeps its two halves in two
+// images of 32-byte rows [half][row][16 k] (one DMA instruction: 32 rows of one half), which need no swizzle:
+// the sixteen lanes a ds_read_b128 services together hold rows m, 12 + m of chunk c and rows 4 + m, 8 + m of
+// chunk c ^ 1 of one half, i.e. slots 2 (row & 7) + chunk of the 256-byte bank row, all different.
+template <int LAY, int NB, int KG> struct RingOperand;
 
-template <int NB> struct RingOperand<0, NB> {
+template <int NB, int KG> struct RingOperand<0, NB, KG> {
     unsigned off[2];
     unsigned addr[2];  // per pair of stages: the offset field of ds_read holds 64 KB
     u4_t frag[2][NB];
@@ -630,19 +636,24 @@ template <int NB> struct RingOperand<0, NB> {
     {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int row = 16 * (2 * wave + j) + (lane >> 2);  // 16 rows of 4 chunks per instruction
-            const int c = (lane & 3) ^ ((0 - (lane >> 4)) & 3);  // the row's XOR term: (row >> 2) & 3 = (lane >> 4) & 3
+            // KG 32: 16 rows of 4 chunks per instruction; the row's XOR term: (row >> 2) & 3 = (lane >> 4) & 3
+            // KG 16: 32 rows of the 2 chunks of one half (instructions 0 - 7: first half)
+            const int row = KG == 32 ? 16 * (2 * wave + j) + (lane >> 2) : 32 * ((2 * wave + j) & 7) + (lane >> 1);
+            const int c = KG == 32 ? (lane & 3) ^ ((0 - (lane >> 4)) & 3) : (lane & 1);
             int64_t g = r0 + row;
             if (g > R - 1) g = R - 1;
             off[j] = (unsigned)(tab[g] * 2 + c * 16);
         }
         const int frow = lane & 15, kg = lane >> 4;  // lane (frow, kg) reads chunk kg of its row
 #pragma unroll
-        for (int h = 0; h < 2; ++h) addr[h] = image + 2 * h * kRingStage + (w0 + frow) * 64 + ((kg ^ ((0 - (frow >> 2)) & 3)) << 4);
+        for (int h = 0; h < 2; ++h)
+            addr[h] = image + 2 * h * kRingStage +
+                      (KG == 32 ? (w0 + frow) * 64 + ((kg ^ ((0 - (frow >> 2)) & 3)) << 4)
+                                : (kg >> 1) * (kRingImage / 2) + (w0 + frow) * 32 + (kg & 1) * 16);
     }
     template <int SLOT, int S, int B> __device__ __forceinline__ void read()
     {
-        lds_read128<(S & 1) * kRingStage + B * 1024>(frag[SLOT][B], addr[S >> 1]);
+        lds_read128<(S & 1) * kRingStage + B * (KG == 32 ? 1024 : 512)>(frag[SLOT][B], addr[S >> 1]);
     }
     template <int SLOT> __device__ __forceinline__ void all_arrived()
     {
@@ -652,7 +663,7 @@ template <int NB> struct RingOperand<0, NB> {
     template <int SLOT, int B> __device__ __forceinline__ bf8_t get() const { return __builtin_bit_cast(bf8_t, frag[SLOT][B]); }
 };
 
-template <int NB> struct RingOperand<1, NB> {
+template <int NB, int KG> struct RingOperand<1, NB, KG> {
     unsigned off[2];
     unsigned addr[2];  // block 0, per pair of stages; block b is at addr ^ 32 b (the XOR term of the swizzle mixes with the block index)
     u2_t lo[2][NB], hi[2][NB];
@@ -665,7 +676,7 @@ template <int NB> struct RingOperand<1, NB> {
             const int c = (lane & 31) ^ (((line & 3) << 2) | (((line >> 3) & 1) << 1));
             int64_t g = r0 + 8 * c;
             if (g > R - 8) g = R - 8;  // R is a multiple of 8 with this layout
-            off[j] = (unsigned)((tab[g] + line * k_in) * 2);
+            off[j] = (unsigned)((tab[g] + (line & (KG - 1)) * k_in) * 2);  // from the table entry of the line's group
         }
         // lane 4 q + pp of lane group g names rows 4 pp .. 4 pp + 3 of line 8 g + q of the block and receives the
         // four lines of row (lane & 15)
@@ -695,7 +706,7 @@ template <int NB> struct RingOperand<1, NB> {
     }
 };
 
-template <int LA, int LB> __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams p)
+template <int LA, int LB, int KG> __global__ void __launch_bounds__(512, 1) gemm_bf16_ring_kernel(const GemmParams p)
 {
     using namespace lds_dma;
     constexpr int BT = 256, BM = BT, BN = BT, TM = 8, TN = 4, NMFMA = TM * TN, NDMA = 4, BK = kRingBK;
@@ -742,8 +753,8 @@ template <int LA, int LB> __global__ void __launch_bounds__(512, 1) gemm_bf16_ri
     const int nk = kt_last - kt_first;
 
     const unsigned smem_lds = lds_addr(smem);
-    RingOperand<LA, TM> opa;
-    RingOperand<LB, TN> opb;
+    RingOperand<LA, TM, KG> opa;
+    RingOperand<LB, TN, KG> opb;
     opa.init(p.row_a, m0, p.M, p.ka_in, smem_lds, wm0, wave, lane);
     opb.init(p.col_b, n0, p.N, p.kb_in, smem_lds + kRingImage, wn0, wave, lane);
 
@@ -759,7 +770,9 @@ template <int LA, int LB> __global__ void __launch_bounds__(512, 1) gemm_bf16_ri
     int tl = 0;
     int64_t ka_next, kb_next;
     auto k_fetch = [&]() {
-        const int64_t *pa = p.k_a + (int64_t)(kt_first + tl) * BK, *pb = p.k_b + (int64_t)(kt_first + tl) * BK;
+        // KG 16: this wave's DMAs all fetch one half of the K-tile (waves 0 - 3 the first): the entry of that half
+        const int64_t k0 = (int64_t)(kt_first + tl) * BK + (KG == 16 ? 16 * (wave >> 2) : 0);
+        const int64_t *pa = p.k_a + k0, *pb = p.k_b + k0;
         asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(ka_next) : "s"(pa));
         asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(kb_next) : "s"(pb));
     };
@@ -855,18 +868,23 @@ template <int LA, int LB> __global__ void __launch_bounds__(512, 1) gemm_bf16_ri
     store_tile_bf16<BT, TM, TN>(p, acc, smem, C, m0, n0, wm0, wn0, t, lane, partial, sid, chunk);
 }
 
-// both operands read in 16-byte vectors, the 256 tile, K a multiple of 32 with k offsets affine inside
-// aligned groups of 32 (step 1 for a K-major operand), lane offsets that fit 32 bits
-bool ring_supported(int la, int lb, int bt, const GemmParams &p)
+// both operands read in 16-byte vectors, the 256 tile, K a multiple of 32 with k offsets affine inside aligned
+// groups of 32 (returns 32) or of 16 (returns 16; not for two outer-major operands), step 1 for a K-major operand,
+// lane offsets that fit 32 bits; 0: the two-buffer kernel
+int ring_group(int la, int lb, int bt, const GemmParams &p)
 {
     static const bool off = getenv("CTC_TC_NO_BF16_RING") != nullptr;
     static const bool no_outer = getenv("CTC_TC_NO_BF16_RING_OUTER") != nullptr;
-    if (off || bt != 256 || la == kLayScalar || lb == kLayScalar || (no_outer && (la != 0 || lb != 0))) return false;
-    if (p.k32_affine == 0 || p.K < kRingBK || p.K % kRingBK != 0) return false;
+    static const bool no_k16 = getenv("CTC_TC_NO_BF16_RING_K16") != nullptr;
+    if (off || bt != 256 || la == kLayScalar || lb == kLayScalar || (no_outer && (la != 0 || lb != 0))) return 0;
+    if (p.K < kRingBK || p.K % kRingBK != 0) return 0;
     const int64_t step_max = int64_t(1) << 22;  // 31 lines of a K-tile stay inside the 32-bit lane offset
-    if (la == 0 ? p.ka_in != 1 : (p.ka_in < 0 || p.ka_in > step_max || p.M < 8)) return false;
-    if (lb == 0 ? p.kb_in != 1 : (p.kb_in < 0 || p.kb_in > step_max || p.N < 8)) return false;
-    return true;
+    if (la == 0 ? p.ka_in != 1 : (p.ka_in < 0 || p.ka_in > step_max || p.M < 8)) return 0;
+    if (lb == 0 ? p.kb_in != 1 : (p.kb_in < 0 || p.kb_in > step_max || p.N < 8)) return 0;
+    if (p.k32_affine != 0) return 32;
+    // (two outer-major operands with groups of 16: that instantiation does not fit the register file)
+    if (p.k16_affine != 0 && !no_k16 && !(la == 1 && lb == 1)) return 16;
+    return 0;
 }
 
 // Sums the K chunks of the split tiles in chunk order and writes C = alpha * sum + beta * C in bf16.
@@ -976,7 +994,7 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
 
 std::atomic<int64_t> g_ring_launches{0};
 
-template <int LA, int LB> hipError_t launch_ring(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
+template <int LA, int LB, int KG> hipError_t launch_ring(const GemmParams &p, const GemmSchedule &sch, void *ws, hipStream_t stream)
 {
     constexpr int BT = 256;
     g_ring_launches.fetch_add(1);
@@ -989,7 +1007,7 @@ template <int LA, int LB> hipError_t launch_ring(const GemmParams &p, const Gemm
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
     if (sch.nbm != (int)((p.M + BT - 1) / BT) || sch.nbn != (int)((p.N + BT - 1) / BT)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_bf16_ring_kernel<LA, LB>), dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1), dim3(2 * BT),
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<LA, LB, KG>), dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1), dim3(2 * BT),
                        0, stream, q);
     if (sch.tail_tiles > 0)
         hipLaunchKernelGGL(splitk_fixup_bf16_kernel<BT>, dim3((unsigned)(sch.tail_tiles * (BT / 16))), dim3(256), 0, stream, q);
@@ -1054,13 +1072,16 @@ hipError_t launch_gemm_bf16(int la, int lb, int bm, const GemmParams &p, const G
 {
     if (la < 0 || la > 2 || lb < 0 || lb > 2) return hipErrorInvalidValue;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || p.batch <= 0 || p.batch > 65535) return hipErrorInvalidValue;
-    if (ring_supported(la, lb, tile_edge(la, lb, bm), p)) {
-        switch (la * 2 + lb) {
-        case 0: return launch_ring<0, 0>(p, sch, ws, stream);
-        case 1: return launch_ring<0, 1>(p, sch, ws, stream);
-        case 2: return launch_ring<1, 0>(p, sch, ws, stream);
-        default: return launch_ring<1, 1>(p, sch, ws, stream);
-        }
+    const int group = ring_group(la, lb, tile_edge(la, lb, bm), p);  // 0 unless both layouts are 0 or 1
+    switch (group == 0 ? -1 : (group / 16) * 4 + la * 2 + lb) {     // group 16: 4 .. 7, 32: 8 .. 11
+    case 4: return launch_ring<0, 0, 16>(p, sch, ws, stream);
+    case 5: return launch_ring<0, 1, 16>(p, sch, ws, stream);
+    case 6: return launch_ring<1, 0, 16>(p, sch, ws, stream);
+    case 8: return launch_ring<0, 0, 32>(p, sch, ws, stream);
+    case 9: return launch_ring<0, 1, 32>(p, sch, ws, stream);
+    case 10: return launch_ring<1, 0, 32>(p, sch, ws, stream);
+    case 11: return launch_ring<1, 1, 32>(p, sch, ws, stream);
+    default: break;
     }
     if (tile_edge(la, lb, bm) == 256) {
         switch (la * 2 + lb) {

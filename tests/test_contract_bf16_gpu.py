@@ -264,6 +264,13 @@ RING_CASES = [
     ("outer_b_two_contracted_modes", "aef,efb->ab", dict(a=392, b=264, e=3, f=64)),
     ("outer_both_batched", "zka,zkb->zab", dict(z=3, a=264, b=328, k=64)),
     ("outer_b_permuted_result", "ak,kb->ba", dict(a=264, b=328, k=64)),
+    # k offsets affine inside aligned groups of 16 only: one table entry per half of a K-tile
+    ("k16_kmajor_both", "aef,ebf->ab", dict(a=392, b=264, e=6, f=16)),
+    ("k16_kmajor_both_48", "aef,ebf->ab", dict(a=300, b=520, e=2, f=48)),
+    ("k16_headline_shape", "aeim,ebmj->abij", dict(a=12, b=10, e=4, i=24, j=32, m=16)),
+    ("k16_headline_shape_80", "aeim,ebmj->abij", dict(a=5, b=6, e=2, i=56, j=48, m=80)),
+    ("k16_outer_a", "efa,ebf->ab", dict(a=392, b=264, e=4, f=16)),
+    ("k16_splitk", "aef,ebf->ab", dict(a=300, b=264, e=64, f=48)),
     ("three_k_tiles_ragged_edges", "ak,bk->ab", dict(a=520, b=392, k=96)),
     ("seven_k_tiles", "ak,bk->ab", dict(a=300, b=777, k=224)),
     ("splitk", "ak,bk->ab", dict(a=300, b=264, k=3072)),
