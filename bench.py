@@ -4,10 +4,12 @@
   python bench.py --gpus N --steps K --warmup W [--extent 96] [--shard free|contracted]
 
 A step is one whole contraction with operands already resident in HBM.  With
-N > 1 (one process per GPU under torch.distributed.run) the contraction grows
-along the free index `a` (extent = N * extent): every rank owns one slab of A
-and of C, B is replicated, no collective touches the data path ("weak" scaling).
-Rank 0 prints one JSON line.
+N > 1 (one process per GPU under torch.distributed.run) the SAME contraction is
+split along the free index `a` (extent / N per rank): every rank owns one slab
+of A and of C, B is replicated, no collective touches the data path, the step
+time is the slowest rank's ("strong" scaling: value(N) / value(1) is the
+speed-up).  The contraction grown with N instead (a = N * extent, "weak") is
+reported under config.variants.  Rank 0 prints one JSON line.
 
 --shard contracted (BASELINE configs[3], second variant) keeps the contraction at all extents
 `extent` and splits the contracted index e over the ranks instead ("strong" scaling): every
@@ -37,7 +39,7 @@ SEED_A, SEED_B = 0xC7C0A, 0xC7C0B
 # fp64 matrix peak of MI355X, dense, public datasheet value (256 CUs x 4 SIMDs x
 # 32 flop/clk x 2.4 GHz); the measured microarchitecture guide lists no fp64 row.
 PEAK_FP64_MFMA_TFLOPS = 78.6
-TRAFFIC_FILE = "r02b_bench_traffic.json"  # counter passes of the kernel the bench currently runs
+TRAFFIC_FILE = "r03_bench_traffic.json"  # counter passes of the kernel the bench currently runs
 
 
 def cpu_baseline(extent, threads):
@@ -94,7 +96,8 @@ def measured_traffic(extent, kernel_summary):
         return None
     with open(path) as f:
         t = json.load(f)
-    if kernel_summary["kernel_name"].split("<")[0] not in t.get("kernel", "") or tuple(kernel_summary["tile"][:2]) != (128, 128):
+    # the passes count for one kernel instantiation: the whole name must agree, template arguments included
+    if kernel_summary["kernel_name"].replace(" ", "") not in t.get("kernel", "").replace(" ", ""):
         return None
     return t["per_launch_bytes"]["total_corrected"]
 
@@ -245,6 +248,7 @@ KEEPER_SOURCE = (
     "    sys.stdout.flush()\n"
 )
 KEEPER = None
+KEEPER_LOCK = threading.Lock()  # the watchdog thread and the main thread both offer lines
 
 
 def start_keeper():
@@ -258,16 +262,19 @@ def start_keeper():
 
 def offer(obj):
     """The line to print unless a later one replaces it."""
-    KEEPER[1].write(json.dumps(obj) + "\n")
-    KEEPER[1].flush()
+    with KEEPER_LOCK:
+        if KEEPER is not None:
+            KEEPER[1].write(json.dumps(obj) + "\n")
+            KEEPER[1].flush()
 
 
 def finish():
     """Closes the keeper's pipe (it prints the last line offered) and waits for it."""
     global KEEPER
-    if KEEPER is not None:
-        proc, w = KEEPER
-        KEEPER = None
+    with KEEPER_LOCK:
+        keeper, KEEPER = KEEPER, None
+    if keeper is not None:
+        proc, w = keeper
         w.close()
         proc.wait()
 
@@ -277,18 +284,57 @@ def emit(obj):
     finish()
 
 
-def watchdog(seconds, rank):
-    """Ends this rank if the secondary measurements do not return (rank 0 prints what it has first).  A
-    thread, not a signal handler: the main thread may be stuck inside a library call."""
+EXIT_VARIANTS_TIMED_OUT = 3
+
+
+def watchdog(seconds, rank, line, state):
+    """Ends this rank, with a non-zero exit status, if the secondary measurements do not return.  Rank 0
+    first prints the headline line with the time-out recorded in config.variants (what had finished stays,
+    the measurement that hung is named), so a collective that hangs is visible both in the record and in
+    the exit status.  A thread, not a signal handler: the main thread may be stuck inside a library call."""
     def fire():
-        sys.stderr.write("bench.py: secondary measurements still running after %d s on rank %d: giving up on them\n" % (seconds, rank))
+        sys.stderr.write("bench.py: secondary measurements still running after %d s on rank %d (in %r): giving up\n"
+                         % (seconds, rank, state.get("running")))
         sys.stderr.flush()
+        if line is not None:
+            variants = dict(state.get("done", {}))
+            variants["timeout"] = {"after_s": seconds, "running": state.get("running"),
+                                   "exit_status": EXIT_VARIANTS_TIMED_OUT}
+            line["config"]["variants"] = variants
+            offer(line)
         finish()
-        os._exit(0)
-    t = threading.Timer(seconds, fire)
+        os._exit(EXIT_VARIANTS_TIMED_OUT)
+    # rank 0 goes first: a launcher that sees another rank fail ends rank 0 before it has recorded the time-out
+    t = threading.Timer(seconds if rank == 0 else seconds + 5.0, fire)
     t.daemon = True
     t.start()
     return t
+
+
+def run_weak(n, world, rank, dev, backend, steps, warmup):
+    """The contraction grown with the job: a = N * n, one slab of n per rank (what every rank computes is
+    the N = 1 headline contraction), no collective: weak scaling."""
+    full = ctc_amd.Plan(SPEC, dict(a=n * world, b=n, i=n, j=n, e=n, m=n), "f64")
+    plan, off_a, _, _ = full.shard("a", rank, world)
+    A = torch.empty(n ** 4, dtype=torch.float64, device=dev)
+    B = torch.empty(n ** 4, dtype=torch.float64, device=dev)
+    C = torch.empty(n ** 4, dtype=torch.float64, device=dev)
+    ctc_amd.fill(A, SEED_A, first=off_a)
+    ctc_amd.fill(B, SEED_B)
+    plan.prepare()
+    for _ in range(warmup):
+        plan.execute(A, B, C)
+    _barrier(world)
+    t0 = time.perf_counter()
+    kernel_ms = plan.time(A, B, C, warmup=0, iters=steps)
+    _barrier(world)
+    elapsed = time.perf_counter() - t0
+    elapsed, kernel_ms = _max_over_ranks([elapsed, kernel_ms], world, dev, backend)
+    flops = 2 * n ** 6 * world
+    return {"workload": "abij=aeim,ebmj fp64, a = %d (= %d x %d), other extents %d, free index a split over %d GPU(s), no collective"
+                        % (n * world, world, n, n, world),
+            "scaling": "weak", "n_gpus": world, "steps": steps, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "tflops": round(flops / (elapsed / steps) * 1e-12, 3), "per_gpu_kernel_ms": round(kernel_ms, 4)}
 
 
 def main():
@@ -308,7 +354,8 @@ def main():
     ap.add_argument("--shard", choices=("free", "contracted"), default="free")
     ap.add_argument("--prewarm", type=float, default=0.1, help="seconds of untimed load before the warm-up steps")
     ap.add_argument("--variant-timeout", type=float, default=240.0,
-                    help="seconds after which the secondary measurements are abandoned (the headline line is printed without them)")
+                    help="seconds after which the secondary measurements are abandoned: the headline line is printed with "
+                         "the time-out recorded in config.variants and the process exits with status %d" % EXIT_VARIANTS_TIMED_OUT)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -332,14 +379,17 @@ def main():
     n = args.extent
     if args.shard == "contracted":
         return bench_contracted(args, world, rank, dev, backend)
-    full_ext = dict(a=n * world, b=n, i=n, j=n, e=n, m=n)
-    full = ctc_amd.Plan(SPEC, full_ext, "f64")
+    if n % world:
+        raise SystemExit("--extent %d is not a multiple of --gpus %d: the free index a is split evenly" % (n, world))
+    # ONE contraction whatever N is: all extents n, the free index a split over the ranks (n / N each)
+    a_loc = n // world
+    full = ctc_amd.Plan(SPEC, dict(a=n, b=n, i=n, j=n, e=n, m=n), "f64")
     plan, off_a, off_b, off_c = full.shard("a", rank, world)
     # each rank holds only its slab of A and C; B is replicated
-    slab_a = n * n * n * n
-    A = torch.empty(slab_a, dtype=torch.float64, device=dev)
+    slab = a_loc * n ** 3
+    A = torch.empty(slab, dtype=torch.float64, device=dev)
     B = torch.empty(n ** 4, dtype=torch.float64, device=dev)
-    C = torch.empty(slab_a, dtype=torch.float64, device=dev)
+    C = torch.empty(slab, dtype=torch.float64, device=dev)
     ctc_amd.fill(A, SEED_A, first=off_a)
     ctc_amd.fill(B, SEED_B)
     plan.prepare()
@@ -359,19 +409,21 @@ def main():
     for _ in range(args.warmup):
         plan.execute(A, B, C)
     barrier()
-    launches_dma_before = ctc_amd.get_option("launches_dma_gemm")
+    counters = ("launches_dma_gemm", "launches_classic", "launches_stream", "launches_stream_f64_dma")
+    launches_before = [ctc_amd.get_option(c) for c in counters]
     t0 = time.perf_counter()
-    # K launches on torch's current stream, bracketed by HIP events on that same stream
-    kernel_ms = plan.time(A, B, C, warmup=0, iters=args.steps)
+    # K launches on torch's current stream, a HIP event on that same stream between every two
+    ms_each = plan.time_each(A, B, C, iters=args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+    kernel_ms = sum(ms_each) / len(ms_each)
+    kernel_ms_median = sorted(ms_each)[len(ms_each) // 2] if len(ms_each) % 2 else \
+        0.5 * (sorted(ms_each)[len(ms_each) // 2 - 1] + sorted(ms_each)[len(ms_each) // 2])
+    elapsed, kernel_ms, kernel_ms_median = _max_over_ranks([elapsed, kernel_ms, kernel_ms_median], world, dev, backend)
 
     flops_rank = plan.flops
-    flops_job = flops_rank * world
+    flops_job = 2 * n ** 6
+    assert flops_rank * world == flops_job
     ms_per_step = elapsed / args.steps * 1e3
     value = flops_job / (elapsed / args.steps) * 1e-12
 
@@ -379,17 +431,19 @@ def main():
     # on C[a, b, :, :] for one a of this rank's slab and three b (fp64 bar: 1e-12 of max |C|).
     rel_err = None
     if not args.no_verify:
-        rel_err = verify_slabs(C, n, rank * n, n // 3, (0, n // 2, n - 1))
-        if world > 1:
-            t = torch.tensor([rel_err], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            rel_err = float(t[0])
+        rel_err = verify_slabs(C, n, rank * a_loc, a_loc // 3, (0, n // 2, n - 1))
+        rel_err = _max_over_ranks([rel_err], world, dev, backend)[0]
 
+    out = None
     if rank == 0:
         s = plan.summary()
-        # which tiled-GEMM kernel the timed launches took (the library counts them)
-        s["kernel_name"] = ("gemm_dma_kernel<double, %d, %d, 64, 1, false>" % (s["layout_a"] != "k_vec", s["layout_b"] != "k_vec")
-                            if ctc_amd.get_option("launches_dma_gemm") > launches_dma_before else "gemm_kernel<double>")
+        # which tiled-GEMM kernel the timed launches took (the library counts them and reports the form)
+        took = [c for c, b in zip(counters, launches_before) if ctc_amd.get_option(c) > b]
+        name, tile = plan.gemm_kernel_name()
+        if took == ["launches_dma_gemm"] or took == ["launches_classic"]:
+            s["kernel_name"], s["kernel_tile"] = name, tile
+        else:
+            s["kernel_name"], s["kernel_tile"] = "+".join(t[9:] for t in took), list(s["tile"])
         achieved = flops_rank / (kernel_ms * 1e-3) * 1e-12
         out = {
             "metric": "achieved TFLOP/s per contraction (fp64, C[a,b,i,j]=A[a,e,i,m]*B[e,b,m,j])",
@@ -400,15 +454,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic (splitmix64 uniform[-1,1), generated in HBM)",
             "config": {
                 "workload": "BASELINE configs[1]: abij=aeim,ebmj fp64, all extents %d%s" % (
-                    n, "" if world == 1 else ", free index a sharded: extent %d over %d GPUs" % (n * world, world)),
-                "gemm_view": {"M": s["M"], "N": s["N"], "K": s["K"]},
-                "tile": [128, 128, 8] if s["kernel_name"].startswith("gemm_dma") else list(s["tile"]), "layout_a": s["layout_a"], "layout_b": s["layout_b"],
+                    n, "" if world == 1 else ", the same contraction split along the free index a over %d GPUs "
+                                             "(%d each), no collective" % (world, a_loc)),
+                "gemm_view_per_gpu": {"M": s["M"], "N": s["N"], "K": s["K"]},
+                "tile": s["kernel_tile"], "layout_a": s["layout_a"], "layout_b": s["layout_b"],
                 "flops_per_step": flops_job,
                 "pct_of_fp64_mfma_peak": round(100.0 * value / (PEAK_FP64_MFMA_TFLOPS * world), 2),
                 "variants": {},
@@ -421,18 +476,23 @@ def main():
                 "frac": round(achieved / PEAK_FP64_MFMA_TFLOPS, 4),
                 "traffic": measured_traffic(n, s) if world == 1 else None,
                 "traffic_unit": "bytes per launch at the L2's memory side (separate counter passes, profiles/%s)" % TRAFFIC_FILE,
-                "algorithmic_bytes_per_launch": 3 * 8 * n ** 4,
+                "algorithmic_bytes_per_launch": 8 * (2 * a_loc * n ** 3 + n ** 4),
                 "kernel": s["kernel_name"],
                 "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_median": round(kernel_ms_median, 4),
+                "frac_from_median": round(flops_rank / (kernel_ms_median * 1e-3) * 1e-12 / PEAK_FP64_MFMA_TFLOPS, 4),
+                "per": "GPU (the slowest rank's launches; every rank runs the same kernel on its slab)",
                 "algorithmic_flops_per_launch": flops_rank,
             },
         }
         if rel_err is not None:
             out["verified"] = bool(rel_err <= 1e-12)
             out["verify"] = {"max_rel_err": rel_err, "tolerance": 1e-12,
-                             "what": "C[a,b,:,:] for a=%d, b in (0,%d,%d) of every rank's result vs the CPU oracle, "
-                                     "after the timed launches" % (n // 3, n // 2, n - 1)}
-        if not args.no_cpu and world == 1:
+                             "what": "C[a,b,:,:] for one a of every rank's slab (its index %d), b in (0,%d,%d), vs the CPU "
+                                     "oracle, after the timed launches" % (a_loc // 3, n // 2, n - 1)}
+        offer(out)  # printed as it stands if anything below takes the process down
+        if not args.no_cpu:
+            # the CPU column, at every N: rank 0's host cores, while the other ranks wait at the next barrier
             threads = cpu_threads()
             tf, dt, _ = cpu_baseline(args.cpu_extent, threads)
             out["cpu_baseline"] = {
@@ -442,25 +502,31 @@ def main():
                           "oracle (OpenMP over the outermost free index, every CPU of this job's share); the "
                           "reference has no CPU contraction path" % (args.cpu_extent, args.cpu_extent, dt),
             }
-        offer(out)  # printed as it stands if the secondary measurements take the process down
+            offer(out)
 
     # Secondary measurements, after and outside the headline's timed region (every rank takes part; a
-    # failure in one of them is reported in its place and does not cost the headline line).
+    # failure in one of them is reported in its place and does not cost the headline line; one that does not
+    # return ends the run with the time-out on record and a non-zero exit status).
     if not args.no_variants:
-        guard = watchdog(args.variant_timeout, rank)
-        variants = {}
+        state = {"running": None, "done": {}}
+        guard = watchdog(args.variant_timeout, rank, out, state)
         del C
         torch.cuda.empty_cache()
-        for name, fn in (("config4_free_index_strong", lambda: run_config4(world, rank, dev, backend, 4, 2)),
-                         ("contracted_index_reduce_scatter", lambda: run_contracted(n, world, rank, dev, backend, 6, 2))):
+        todo = [("config4_free_index_strong", lambda: run_config4(world, rank, dev, backend, 4, 2)),
+                ("contracted_index_reduce_scatter", lambda: run_contracted(n, world, rank, dev, backend, 6, 2))]
+        if world > 1:
+            todo.insert(0, ("free_index_weak", lambda: run_weak(n, world, rank, dev, backend, args.steps, args.warmup)))
+        for name, fn in todo:
+            state["running"] = name
             try:
-                variants[name] = fn()
+                state["done"][name] = fn()
             except Exception as e:  # noqa: BLE001
-                variants[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                state["done"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
+        state["running"] = None
         guard.cancel()
         if rank == 0:
-            out["config"]["variants"] = variants
+            out["config"]["variants"] = state["done"]
             offer(out)
     if rank == 0:
         finish()

@@ -15,7 +15,7 @@ SYMBOLS = (
     "ctc_tc_version", "ctc_tc_last_error", "ctc_tc_device_count",
     "ctc_tc_plan_create", "ctc_tc_plan_destroy", "ctc_tc_plan_describe", "ctc_tc_plan_get",
     "ctc_tc_plan_shard", "ctc_tc_plan_prepare", "ctc_tc_execute", "ctc_tc_permute",
-    "ctc_tc_ttgt_workspace_bytes", "ctc_tc_execute_ttgt", "ctc_tc_fill", "ctc_tc_time_execute",
+    "ctc_tc_ttgt_workspace_bytes", "ctc_tc_execute_ttgt", "ctc_tc_fill", "ctc_tc_time_execute", "ctc_tc_time_execute_each",
     "ctc_tc_grouped_contract", "ctc_tc_execute_noalloc", "ctc_tc_noalloc_scratch_bytes", "ctc_tc_set_option", "ctc_tc_get_option",
 )
 # contracted-mode sharding over RCCL (also declared in include/ctc_tc.h)
@@ -104,6 +104,9 @@ def load():
     L.ctc_tc_time_execute.restype = ctypes.c_int
     L.ctc_tc_time_execute.argtypes = [vp, ctypes.c_double, vp, vp, ctypes.c_double, vp, vp,
                                       ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    L.ctc_tc_time_execute_each.restype = ctypes.c_int
+    L.ctc_tc_time_execute_each.argtypes = [vp, ctypes.c_double, vp, vp, ctypes.c_double, vp, vp,
+                                           ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
     L.ctc_tc_comm_unique_id.restype = ctypes.c_int
     L.ctc_tc_comm_unique_id.argtypes = [vp]
     L.ctc_tc_comm_init_rank.restype = ctypes.c_int

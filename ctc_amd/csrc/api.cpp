@@ -262,14 +262,15 @@ bool plan_dma_ok(const ctc::Plan &p)
 bool plan_k8_affine(const ctc::Plan &p) { return plan_dma_ok(p) && p.k8_affine; }
 std::atomic<int64_t> g_stream_max_k{getenv("CTC_TC_STREAM_MAX_K") ? atoll(getenv("CTC_TC_STREAM_MAX_K")) : kStreamMaxK};
 
-// The split-K workspace a tiled-GEMM plan can ask for on the current device: the largest over the
-// layout variants an execution may fall back to (unaligned operand bases take element loads).
-size_t worst_splitk_bytes(const ctc::Plan &p)
+// The part of a launch's parameters that comes from the plan alone (shape, what the LDS-DMA kernels need
+// to know about the k tables): everything schedule_gemm looks at.  One place, so that a schedule reported
+// ahead of time (ctc_tc_plan_prepare, CTC_TC_Q_SCHEDULE) is the schedule of the kernel the launch takes.
+void shape_from_plan(const ctc::Plan &p, int nbatch, ctc::GemmParams &g)
 {
-    if (p.kernel != ctc::kKernelGemm) return 0;
-    ctc::GemmParams g;
     g.M = p.M; g.N = p.N; g.K = p.K;
-    g.batch = (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch);
+    g.batch = nbatch;
+    g.group = p.tile.group;
+    // one table entry per K-tile of 8 and 32-bit lane offsets: what the LDS-DMA kernel needs
     g.k8_affine = plan_k8_affine(p) ? 1 : 0;
     g.k4_affine = (plan_dma_ok(p) && p.k4_affine) ? 1 : 0;
     g.k16_affine = (g.k8_affine && p.k16_affine) ? 1 : 0;
@@ -277,6 +278,15 @@ size_t worst_splitk_bytes(const ctc::Plan &p)
     g.ka_in = p.ka_in;
     g.kb_in = p.kb_in;
     g.k_run = plan_dma_ok(p) ? p.k_run : 0;
+}
+
+// The split-K workspace a tiled-GEMM plan can ask for on the current device: the largest over the
+// layout variants an execution may fall back to (unaligned operand bases take element loads).
+size_t worst_splitk_bytes(const ctc::Plan &p)
+{
+    if (p.kernel != ctc::kKernelGemm) return 0;
+    ctc::GemmParams g;
+    shape_from_plan(p, (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch), g);
     size_t worst = 0;
     for (int va = 0; va < 2; ++va)
         for (int vb = 0; vb < 2; ++vb) {
@@ -336,23 +346,12 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     g.row_a = t.row_a; g.k_a = t.k_a; g.k_b = t.k_b; g.col_b = t.col_b;
     g.row_c = t.row_c; g.col_c = t.col_c;
     g.bat_a = t.bat_a + b0; g.bat_b = t.bat_b + b0; g.bat_c = t.bat_c + b0;
-    g.M = p.M; g.N = p.N; g.K = p.K;
-    g.batch = nb;
+    shape_from_plan(p, nb, g);
     g.alpha = alpha; g.beta = beta;
-    g.group = p.tile.group;
     // 16-byte stores of C need an aligned base as well
     g.c_vec = (p.vec_c > 1 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) ? p.vec_c : 1;
     // a result larger than the 256 MiB Infinity Cache cannot stay resident for a consumer anyway
     g.c_stream = (double)p.M * (double)p.N * (double)p.batch * (double)ctc::dtype_size(p.dtype) > 256.0 * 1048576.0;
-
-    // one table entry per K-tile of 8 and 32-bit lane offsets: what the LDS-DMA kernel needs
-    g.k8_affine = plan_k8_affine(p) ? 1 : 0;
-    g.k4_affine = (plan_dma_ok(p) && p.k4_affine) ? 1 : 0;
-    g.k16_affine = (g.k8_affine && p.k16_affine) ? 1 : 0;
-    g.k32_affine = (g.k16_affine && p.k32_affine) ? 1 : 0;
-    g.ka_in = p.ka_in;
-    g.kb_in = p.kb_in;
-    g.k_run = plan_dma_ok(p) ? p.k_run : 0;
 
     // vector loads need 16-byte aligned bases; otherwise fall back to element loads
     int la = p.layout_a, lb = p.layout_b;
@@ -371,11 +370,16 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
             g.ka_stride = p.ka_stride;
             g.kb_stride = p.kb_stride;
             const bool dma = p.dtype == ctc::kF64 && g_stream_f64_dma.load() != 0 && ctc::stream_gemm_f64_dma_supported(la, lb, g);
-            hipError_t es = dma ? ctc::launch_gemm_stream_f64_dma(la, lb, g, stream)
-                                : ctc::launch_gemm_stream(p.dtype, la, lb, g, stream);
-            if (es != hipSuccess) return fail_hip(es, "persistent contraction kernel launch");
-            (dma ? g_launches_stream_dma : g_launches_stream).fetch_add(1);
-            continue;
+            // fp64 without the LDS-DMA form (a K that is no multiple of its K-tile, k offsets with more than one
+            // stride): the register-staged persistent form is slower than the one-tile-per-workgroup kernels
+            // (K = 40 under 31,250 tiles: 19.8 against 36.6 TFLOP/s), so only a forced mode takes it
+            if (dma || p.dtype != ctc::kF64 || force) {
+                hipError_t es = dma ? ctc::launch_gemm_stream_f64_dma(la, lb, g, stream)
+                                    : ctc::launch_gemm_stream(p.dtype, la, lb, g, stream);
+                if (es != hipSuccess) return fail_hip(es, "persistent contraction kernel launch");
+                (dma ? g_launches_stream_dma : g_launches_stream).fetch_add(1);
+                continue;
+            }
         }
     }
 
@@ -431,7 +435,7 @@ namespace {
 constexpr size_t kScratchBytes = size_t(128) << 20;
 constexpr int kMaxDevices = 64;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
-void *g_scratch_ptr[kMaxDevices] = {};
+std::atomic<void *> g_scratch_ptr[kMaxDevices];  // written once per device (scratch_setup), read by every execution
 std::mutex g_scratch_mu;
 
 // caller has made `device` current
@@ -439,11 +443,11 @@ int scratch_setup(int device)
 {
     if (device < 0 || device >= kMaxDevices) return CTC_TC_OK;  // such a device simply has no no-alloc path
     std::lock_guard<std::mutex> lock(g_scratch_mu);
-    if (g_scratch_ptr[device]) return CTC_TC_OK;
+    if (g_scratch_ptr[device].load()) return CTC_TC_OK;
     void *ptr = nullptr;
     hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess) return fail_hip(e, "hipGetSymbolAddress(scratch)");
-    g_scratch_ptr[device] = ptr;
+    g_scratch_ptr[device].store(ptr);
     return CTC_TC_OK;
 }
 
@@ -625,13 +629,16 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
         int device = 0;
         int rc = current_device(device);
         if (rc) return rc;
+        // the schedule of the kernel a launch with aligned operand bases takes (launch_plan fills the same
+        // fields from the plan), and the largest workspace over the fall-backs to element loads
         ctc::GemmParams g;
-        g.M = p.M; g.N = p.N; g.K = p.K;
-        g.batch = (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch);
+        shape_from_plan(p, (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch), g);
         ctc::GemmSchedule sch;
         hipError_t e = ctc::schedule_gemm(p.dtype, p.layout_a, p.layout_b, p.tile.bm, p.tile.bn, g, &sch);
         if (e != hipSuccess) return fail_hip(e, "contraction schedule");
-        v = {sch.nbm, sch.nbn, sch.dp_tiles, sch.tail_tiles, sch.split, (int64_t)sch.ws_bytes};
+        v = {sch.nbm, sch.nbn, sch.dp_tiles, sch.tail_tiles, sch.split, (int64_t)sch.ws_bytes,
+             (int64_t)ctc::dma_gemm_kind(p.dtype, p.layout_a, p.layout_b, p.tile.bm, p.tile.bn, g),
+             (int64_t)worst_splitk_bytes(p)};
         break;
     }
     default: return fail(CTC_TC_EINVAL, "unknown query");
@@ -742,13 +749,17 @@ int ctc_tc_execute_noalloc(ctc_tc_plan *plan, double alpha, const void *A, const
     int device = 0;
     int rc = current_device(device);
     if (rc) return rc;
-    if (device < 0 || device >= kMaxDevices || g_scratch_ptr[device] == nullptr)
+    if (device < 0 || device >= kMaxDevices)
+        return fail(CTC_TC_EUNSUPPORTED, "ctc_tc_execute_noalloc: device ordinal " + std::to_string(device) +
+                                             " is beyond the " + std::to_string(kMaxDevices) + " devices the fixed scratch buffers cover");
+    void *const scratch_dev = g_scratch_ptr[device].load();
+    if (scratch_dev == nullptr)
         return fail(CTC_TC_EINVAL, "ctc_tc_execute_noalloc: call ctc_tc_plan_prepare on this device first "
                                    "(it resolves the scratch buffer's address and uploads the plan's tables)");
     // always the fused kernel (a plan that prefers explicit transposes would need three packed tensors
     // of workspace); split-K partial sums go to this device's fixed scratch buffer
     ctc_internal::Workspace ws;
-    ws.fixed = g_scratch_ptr[device];
+    ws.fixed = scratch_dev;
     ws.fixed_bytes = kScratchBytes;
     return launch_plan(plan, alpha, A, B, beta, C, static_cast<hipStream_t>(stream), &ws, /*no_alloc=*/true);
 }
@@ -870,6 +881,36 @@ int ctc_tc_time_execute(ctc_tc_plan *plan, double alpha, const void *A, const vo
     if (rc) return rc;
     if (e != hipSuccess) return fail_hip(e, "event timing");
     *avg_ms = (double)ms / iters;
+    return CTC_TC_OK;
+}
+
+int ctc_tc_time_execute_each(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta,
+                             void *C, void *stream, int iters, double *ms_each)
+{
+    if (!plan || !ms_each || iters <= 0 || iters > 4096) return fail(CTC_TC_EINVAL, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<hipEvent_t> ev((size_t)iters + 1, nullptr);
+    hipError_t e = hipSuccess;
+    for (auto &x : ev)
+        if (e == hipSuccess) e = hipEventCreate(&x);
+    int rc = CTC_TC_OK;
+    if (e == hipSuccess) {
+        (void)hipEventRecord(ev[0], s);
+        for (int i = 0; i < iters && rc == CTC_TC_OK; ++i) {
+            rc = ctc_tc_execute(plan, alpha, A, B, beta, C, stream);
+            (void)hipEventRecord(ev[(size_t)i + 1], s);
+        }
+        e = hipEventSynchronize(ev[(size_t)iters]);
+        for (int i = 0; i < iters && e == hipSuccess && rc == CTC_TC_OK; ++i) {
+            float ms = 0.f;
+            e = hipEventElapsedTime(&ms, ev[(size_t)i], ev[(size_t)i + 1]);
+            ms_each[i] = (double)ms;
+        }
+    }
+    for (auto x : ev)
+        if (x) (void)hipEventDestroy(x);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail_hip(e, "event timing");
     return CTC_TC_OK;
 }
 

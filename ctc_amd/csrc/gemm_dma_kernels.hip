@@ -603,6 +603,11 @@ bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, c
     return dma_gemm_geometry(dtype, layout_a, layout_b, bm, bn, p) != 0;
 }
 
+int dma_gemm_kind(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
+{
+    return dma_gemm_geometry(dtype, layout_a, layout_b, bm, bn, p);
+}
+
 // bm / bn are the 128 x 128 tile here: the callers have asked dma_gemm_supported
 hipError_t schedule_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out)
 {

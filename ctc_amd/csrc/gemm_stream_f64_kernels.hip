@@ -18,9 +18,14 @@
 //     tables into an LDS ring by DMA as well, two items ahead.
 // The only ordinary vector-memory instructions left are the stores of C, so the in-order memory
 // counter never makes a wave wait for a store on the way to its operands.
-// Needs vector layouts on both operands, alpha == 1, beta == 0, batch == 1, even M and N, K a multiple of
-// 32 and at least 64, and k offsets that are a multiple of k (one contracted mode, or modes that fuse:
+// Needs vector layouts on both operands, beta == 0, batch == 1, even M and N, K a multiple of the K-tile
+// and at least 64, and k offsets that are a multiple of k (one contracted mode, or modes that fuse:
 // ka_stride / kb_stride); everything else takes the register-staged form or the classic kernel.
+//
+// This file is compiled once per kernel instantiation (each takes minutes: -DCTC_SX_PART=1..10 selects one
+// of the five layout / K-tile combinations, with or without the alpha multiply) plus once for the
+// dispatcher (-DCTC_SX_PART=0), so that the parts build in parallel; without the macro it is one
+// translation unit holding everything.
 #include "gemm_device.hpp"
 #include "kernels.hpp"
 #include "lds_dma.hpp"
@@ -30,8 +35,17 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef CTC_SX_PART
+#define CTC_SX_PART (-1)
+#endif
+
 namespace ctc {
 
+namespace stream_f64 {
+template <int LA, int LB, int BK, bool SCALE> hipError_t launch_scaled(const GemmParams &p, hipStream_t stream);
+}
+
+#if CTC_SX_PART != 0
 namespace {
 
 using namespace gemm_detail;
@@ -158,7 +172,9 @@ template <int LAY, int BR> struct FragAddr {
     template <int b, int kk> static constexpr int imm() { return KMAJ ? b * 16 * 256 : 128 * b + kk * 4 * BR * 8; }
 };
 
-template <int LA, int LB, int BK>
+// SCALE: alpha != 1, applied to each element on its way out (one fp64 multiply per store; the
+// instantiations for alpha == 1 carry none)
+template <int LA, int LB, int BK, bool SCALE>
 __global__ void __launch_bounds__(256, Geom<BK>::kTwoPerCu ? 2 : 1) gemm_stream_f64_kernel(const GemmParams p)
 {
     typedef Geom<BK> G_;
@@ -323,9 +339,9 @@ __global__ void __launch_bounds__(256, Geom<BK>::kTwoPerCu ? 2 : 1) gemm_stream_
     // instruction writing 128 contiguous bytes of four rows.  Per store the vector ALU computes one 64-bit
     // add (row offset, read from the ring a store ahead, onto the lane's column pointer); the 16-byte
     // form would cost four register moves, two lane exchanges and four selects per store, and a wave that
-    // feeds the matrix pipe has about sixteen issue slots per MFMA.  alpha == 1 here (anything else takes
-    // the register-staged form), and the stores are always non-temporal: the launcher sends only results
-    // far larger than the Infinity Cache here.
+    // feeds the matrix pipe has about sixteen issue slots per MFMA.  The stores are always non-temporal: the
+    // launcher sends only results far larger than the Infinity Cache here.
+    const double alpha = p.alpha;
     constexpr int NSTORE = TM * 4 * TN;  // per wave and item
     constexpr int SPT = NSTORE / STORE_TILES, SPACING = NIDX / SPT;
     static_assert(NSTORE % STORE_TILES == 0 && NIDX % SPT == 0 && SPACING >= 2, "store schedule");
@@ -387,7 +403,9 @@ __global__ void __launch_bounds__(256, Geom<BK>::kTwoPerCu ? 2 : 1) gemm_stream_
 #if defined(CTC_SX_NOSTORE)
         ok = ok && acc[SET][i][j][r] == 1.2345e300;
 #endif
-        if (ok) __builtin_nontemporal_store(acc[SET][i][j][r], dst);
+        double v = acc[SET][i][j][r];
+        if (SCALE) v *= alpha;
+        if (ok) __builtin_nontemporal_store(v, dst);
     };
 
 #ifdef CTC_SX_STAMPS  // diagnostic build: shader-clock ticks per K-tile kind, split at the wait + barrier
@@ -545,7 +563,7 @@ __global__ void __launch_bounds__(256, Geom<BK>::kTwoPerCu ? 2 : 1) gemm_stream_
                 for (int j = 0; j < TN; ++j) {
                     const int col = wn0 + 16 * j + frow;
                     if (row < m_lim_prev && col < n_lim_prev)
-                        __builtin_nontemporal_store(acc[SET][i][j][r], C + ro + slot[BM + col]);
+                        __builtin_nontemporal_store(SCALE ? acc[SET][i][j][r] * alpha : acc[SET][i][j][r], C + ro + slot[BM + col]);
                 }
             }
     };
@@ -569,7 +587,7 @@ __global__ void __launch_bounds__(256, Geom<BK>::kTwoPerCu ? 2 : 1) gemm_stream_
 }
 
 // workgroups of the current device that are resident at once, per kernel instantiation
-template <int LA, int LB, int BK> hipError_t resident_workgroups(int *out)
+template <int LA, int LB, int BK, bool SCALE> hipError_t resident_workgroups(int *out)
 {
     static std::atomic<int> cache[64];  // 0: not queried yet
     int dev = 0;
@@ -580,7 +598,7 @@ template <int LA, int LB, int BK> hipError_t resident_workgroups(int *out)
         int cus = 0, per_cu = 0;
         e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_stream_f64_kernel<LA, LB, BK>, 256, 0);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_stream_f64_kernel<LA, LB, BK, SCALE>, 256, 0);
         if (e != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 2) per_cu = 2;
@@ -590,10 +608,12 @@ template <int LA, int LB, int BK> hipError_t resident_workgroups(int *out)
     return hipSuccess;
 }
 
-template <int LA, int LB, int BK> hipError_t launch_one(const GemmParams &p, hipStream_t stream)
+}  // namespace
+
+template <int LA, int LB, int BK, bool SCALE> hipError_t stream_f64::launch_scaled(const GemmParams &p, hipStream_t stream)
 {
     int slots = 0;
-    hipError_t e = resident_workgroups<LA, LB, BK>(&slots);
+    hipError_t e = resident_workgroups<LA, LB, BK, SCALE>(&slots);
     if (e != hipSuccess) return e;
     GemmParams q = p;
     q.nbm = (int)((p.M + kBM - 1) / kBM);
@@ -602,12 +622,49 @@ template <int LA, int LB, int BK> hipError_t launch_one(const GemmParams &p, hip
     const int64_t tiles = (int64_t)q.nbm * q.nbn;
     if (tiles > 0x7FFFFFFF) return hipErrorInvalidValue;
     const int grid = (int)(tiles < slots ? tiles : slots);
-    hipLaunchKernelGGL((gemm_stream_f64_kernel<LA, LB, BK>), dim3((unsigned)grid), dim3(256), 0, stream, q);
+    hipLaunchKernelGGL((gemm_stream_f64_kernel<LA, LB, BK, SCALE>), dim3((unsigned)grid), dim3(256), 0, stream, q);
     return hipGetLastError();
 }
 
-}  // namespace
+// one explicit instantiation per part (all of them when the file is compiled as one translation unit)
+#define CTC_SX_INSTANTIATE(LA_, LB_, BK_, SC_) \
+    template hipError_t stream_f64::launch_scaled<LA_, LB_, BK_, SC_>(const GemmParams &, hipStream_t);
+#if CTC_SX_PART < 0 || CTC_SX_PART == 1
+CTC_SX_INSTANTIATE(1, 1, 16, false)
+#endif
+#if CTC_SX_PART < 0 || CTC_SX_PART == 2
+CTC_SX_INSTANTIATE(1, 1, 16, true)
+#endif
+#ifndef CTC_SX_ONE  // diagnostic builds of the outer/outer, K-tile 16 instantiation only (tools/build_variant.sh)
+#if CTC_SX_PART < 0 || CTC_SX_PART == 3
+CTC_SX_INSTANTIATE(1, 1, 32, false)
+#endif
+#if CTC_SX_PART < 0 || CTC_SX_PART == 4
+CTC_SX_INSTANTIATE(1, 1, 32, true)
+#endif
+#if CTC_SX_PART < 0 || CTC_SX_PART == 5
+CTC_SX_INSTANTIATE(0, 0, 32, false)
+#endif
+#if CTC_SX_PART < 0 || CTC_SX_PART == 6
+CTC_SX_INSTANTIATE(0, 0, 32, true)
+#endif
+#if CTC_SX_PART < 0 || CTC_SX_PART == 7
+CTC_SX_INSTANTIATE(0, 1, 32, false)
+#endif
+#if CTC_SX_PART < 0 || CTC_SX_PART == 8
+CTC_SX_INSTANTIATE(0, 1, 32, true)
+#endif
+#if CTC_SX_PART < 0 || CTC_SX_PART == 9
+CTC_SX_INSTANTIATE(1, 0, 32, false)
+#endif
+#if CTC_SX_PART < 0 || CTC_SX_PART == 10
+CTC_SX_INSTANTIATE(1, 0, 32, true)
+#endif
+#endif
+#undef CTC_SX_INSTANTIATE
+#endif  // CTC_SX_PART != 0
 
+#if CTC_SX_PART <= 0
 // diagnostic switch: CTC_TC_STREAM_BK=32 keeps the one-workgroup-per-CU geometry for every layout
 static int stream_bk()
 {
@@ -617,23 +674,36 @@ static int stream_bk()
 
 bool stream_gemm_f64_dma_supported(int layout_a, int layout_b, const GemmParams &p)
 {
+    // K: whole K-tiles, and at least the 64 contracted elements whose K-tiles carry the previous item's stores
+    const int bk = (layout_a == 1 && layout_b == 1) ? stream_bk() : 32;
     return (layout_a == 0 || layout_a == 1) && (layout_b == 0 || layout_b == 1) && p.batch == 1 && p.beta == 0.0 &&
-           p.alpha == 1.0 && p.K > 32 && p.K % 32 == 0 && p.M >= 2 && p.N >= 2 && p.M % 2 == 0 && p.N % 2 == 0 &&
+           p.K >= 64 && p.K % bk == 0 && p.M >= 2 && p.N >= 2 && p.M % 2 == 0 && p.N % 2 == 0 &&
            p.ka_stride > 0 && p.kb_stride > 0;
 }
+
+namespace {
+template <int LA, int LB, int BK> hipError_t launch_one(const GemmParams &p, hipStream_t stream)
+{
+    return p.alpha == 1.0 ? stream_f64::launch_scaled<LA, LB, BK, false>(p, stream)
+                          : stream_f64::launch_scaled<LA, LB, BK, true>(p, stream);
+}
+}  // namespace
 
 hipError_t launch_gemm_stream_f64_dma(int layout_a, int layout_b, const GemmParams &p, hipStream_t stream)
 {
     if (!stream_gemm_f64_dma_supported(layout_a, layout_b, p)) return hipErrorInvalidValue;
     switch (layout_a * 2 + layout_b) {
-#ifndef CTC_SX_ONE  // diagnostic builds of the outer/outer instantiation only (tools/build_variant.sh)
+#ifndef CTC_SX_ONE
     case 0: return launch_one<0, 0, 32>(p, stream);
     case 1: return launch_one<0, 1, 32>(p, stream);
     case 2: return launch_one<1, 0, 32>(p, stream);
-#endif
     case 3: return stream_bk() == 32 ? launch_one<1, 1, 32>(p, stream) : launch_one<1, 1, 16>(p, stream);
+#else
+    case 3: return launch_one<1, 1, 16>(p, stream);
+#endif
     default: return hipErrorInvalidValue;
     }
 }
+#endif  // CTC_SX_PART <= 0
 
 }  // namespace ctc

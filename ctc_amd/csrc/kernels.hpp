@@ -75,6 +75,9 @@ hipError_t launch_gemm_stream_f64_dma(int layout_a, int layout_b, const GemmPara
 // route to it when dma_gemm_supported says the launch qualifies (vector layouts, k tables affine in aligned
 // groups of at least half a K-tile: k4_affine / k8_affine / k16_affine).
 bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p);
+// which form of it the launch takes: 0 none (the register-staged kernel runs), 1 K-tiles of 64-byte rows,
+// 2 two images of 32-byte rows per stage, 3 one image of 32-byte rows, 4 64-byte rows with ragged K-tiles
+int dma_gemm_kind(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p);
 hipError_t schedule_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, GemmSchedule *out);
 hipError_t launch_gemm_dma(int dtype, int layout_a, int layout_b, const GemmParams &p, const GemmSchedule &schedule,
                            void *workspace, hipStream_t stream);

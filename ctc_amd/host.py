@@ -149,9 +149,25 @@ class Plan:
     def schedule(self):
         """How the current device will run the tiles (needs a GPU): tiles run whole, tiles of the last,
         partly filled round cut along K, chunks per such tile, workspace bytes."""
-        nbm, nbn, whole, tail, split, ws = self.get(_lib.Q_SCHEDULE)
+        nbm, nbn, whole, tail, split, ws, form, ws_worst = self.get(_lib.Q_SCHEDULE)
         return {"tile_rows": nbm, "tile_cols": nbn, "whole_tiles": whole, "tail_tiles": tail, "split": split,
-                "workspace_bytes": ws}
+                "workspace_bytes": ws, "dma_form": form, "workspace_bytes_worst": ws_worst}
+
+    # DMA forms of the tiled GEMM (CTC_TC_Q_SCHEDULE): bytes of k per image row, images per operand and stage, ragged
+    _DMA_FORMS = {1: (64, 1, "false"), 2: (32, 2, "false"), 3: (32, 1, "false"), 4: (64, 1, "true")}
+
+    def gemm_kernel_name(self):
+        """Name (as a profiler prints it) and K-tile of the tiled-GEMM kernel a launch of this plan with aligned
+        operands takes on the current device when neither the persistent nor a skinny kernel claims it."""
+        s = self.summary()
+        ctype = {F64: "double", F32: "float"}.get(self.dtype)
+        form = self.schedule()["dma_form"] if ctype else 0
+        if form:
+            rb, nsub, ragged = self._DMA_FORMS[form]
+            name = "gemm_dma_kernel<%s, %d, %d, %d, %d, %s>" % (ctype, s["layout_a"] != "k_vec", s["layout_b"] != "k_vec",
+                                                                  rb, nsub, ragged)
+            return name, [128, 128, nsub * rb // DTYPE_SIZE[self.dtype]]
+        return ("gemm_kernel<%s>" % ctype if ctype else "gemm_bf16_kernel"), list(s["tile"])
 
     # ---- sharding ----------------------------------------------------------
     def shard(self, mode, rank, nranks):
@@ -195,6 +211,13 @@ class Plan:
         check(self._lib.ctc_tc_time_execute(self._h, float(alpha), _ptr(A), _ptr(B), float(beta), _ptr(C),
                                             _stream(stream), warmup, iters, ctypes.byref(ms)))
         return ms.value
+
+    def time_each(self, A, B, C, iters=10, alpha=1.0, beta=0.0, stream=None):
+        """Device milliseconds of each of `iters` back-to-back executions (an event between every two)."""
+        ms = (ctypes.c_double * iters)()
+        check(self._lib.ctc_tc_time_execute_each(self._h, float(alpha), _ptr(A), _ptr(B), float(beta), _ptr(C),
+                                                 _stream(stream), iters, ms))
+        return [float(x) for x in ms]
 
 
 def contract(spec, A, B, out=None, alpha=1.0, beta=0.0, stream=None):

@@ -94,8 +94,13 @@ enum ctc_tc_query {
     CTC_TC_Q_BAT_B = 24,
     CTC_TC_Q_BAT_C = 25,
     CTC_TC_Q_FLOPS = 26,       /* {2*M*N*K*batch} */
-    CTC_TC_Q_SCHEDULE = 27     /* needs a HIP device: {tile rows, tile columns, tiles run whole, tiles of the last round
-                                  that are cut along K, chunks per such tile, workspace bytes} */
+    CTC_TC_Q_SCHEDULE = 27     /* needs a HIP device.  How a launch with 16-byte aligned operand bases runs on the
+                                  current device: {tile rows, tile columns, tiles run whole, tiles of the last round
+                                  that are cut along K, chunks per such tile, workspace bytes of that launch,
+                                  kernel form (0: operands staged through registers; 1-4: staged by LDS-DMA with
+                                  K-tiles of 64-byte rows / two images of 32-byte rows / one image of 32-byte rows /
+                                  64-byte rows with ragged K-tiles), largest workspace bytes over the launch and its
+                                  fall-backs to element loads for unaligned bases} */
 };
 
 /* operand layouts reported in CTC_TC_Q_TILE */
@@ -336,6 +341,11 @@ int ctc_tc_fill(void *dev, int64_t n, uint64_t seed, int64_t first, int dtype, v
 int ctc_tc_time_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B,
                         double beta, void *C, void *stream, int warmup, int iters,
                         double *avg_ms);
+/* The same with one event between every two executions: ms_each[i] = device time of execution i
+ * (iters <= 4096 values), so that a caller can report a median beside the average.  No reference
+ * counterpart. */
+int ctc_tc_time_execute_each(ctc_tc_plan *plan, double alpha, const void *A, const void *B,
+                             double beta, void *C, void *stream, int iters, double *ms_each);
 
 #ifdef __cplusplus
 }

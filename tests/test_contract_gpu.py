@@ -93,6 +93,45 @@ def test_against_oracle(cuda, oracle, name, spec, ext, dtype):
     _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE[dtype]), dtype)
 
 
+def test_config3_adversarial_contraction_at_full_size(cuda, oracle):
+    """The transpose-bound contraction at the size the measurements quote: abcd = dkca,bk fp32 with
+    a = c = d = 128, b = k = 8 (64 MiB per large tensor, 0.27 Gflop: seconds for the oracle)."""
+    spec, ext = "dkca,bk->abcd", dict(a=128, b=8, c=128, d=128, k=8)
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, "f32", cuda)
+    dC = torch.full((n_out,), float("nan"), dtype=torch.float32, device=cuda)
+    plan = ctc_amd.Plan(spec, ext, "f32")
+    assert plan.summary()["kernel"].startswith("skinny"), plan.summary()
+    plan.execute(dA, dB, dC)
+    _check(dC.cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE["f32"]), "f32")
+
+
+def test_headline_contraction_at_extent_96_slabs(cuda, oracle):
+    """abij = aeim,ebmj fp64 at all extents 96 (1.57e12 flop: far too much for the oracle as a whole):
+    three C[a0, b0, :, :] slabs of the result are recomputed by the oracle from regenerated operands, and
+    the launch must have taken the LDS-DMA kernel with K-tiles of 64-byte rows."""
+    n = 96
+    spec, ext = "aeim,ebmj->abij", dict(a=n, b=n, i=n, j=n, e=n, m=n)
+    dA = torch.empty(n ** 4, dtype=torch.float64, device=cuda)
+    dB = torch.empty(n ** 4, dtype=torch.float64, device=cuda)
+    ctc_amd.fill(dA, 0xC7C0A)
+    ctc_amd.fill(dB, 0xC7C0B)
+    dC = torch.full((n ** 4,), float("nan"), dtype=torch.float64, device=cuda)
+    plan = ctc_amd.Plan(spec, ext, "f64")
+    assert plan.schedule()["dma_form"] == 1
+    before = ctc_amd.get_option("launches_dma_gemm")
+    plan.execute(dA, dB, dC)
+    torch.cuda.synchronize()
+    assert ctc_amd.get_option("launches_dma_gemm") == before + 1
+    assert not bool(torch.isnan(dC).any())
+    B = oracle.fill(n ** 4, 0xC7C0B).reshape(n, n, n, n)
+    got = dC.reshape(n, n, n * n)
+    for a0, b0 in ((0, 0), (n // 3, n // 2), (n - 1, n - 1)):
+        A1 = oracle.fill(n ** 3, 0xC7C0A + a0 * n ** 3)  # A[a0] is n^3 consecutive elements of the stream
+        want = oracle.contract(spec, dict(a=1, b=1, i=n, j=n, e=n, m=n), A1,
+                               np.ascontiguousarray(B[:, b0:b0 + 1]).reshape(-1))
+        _check(got[a0, b0].cpu().numpy(), want, "f64")
+
+
 # Short contracted extent, many tiles: the epilogue (16-byte stores of C through the offset
 # tables kept in LDS) carries as much weight as the K loop.  Ragged edges, K tails, every
 # staging layout, batches.

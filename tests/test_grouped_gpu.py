@@ -43,7 +43,8 @@ def _run(cuda, oracle, dims, code, alpha=1.0, beta=0.0):
 
 @pytest.mark.parametrize("code", [0, 1])
 def test_config5_extents(cuda, oracle, code):
-    _run(cuda, oracle, _problem_set(0xC7C05, 512, [8, 16, 24, 32]), code)
+    """The whole configuration: 4096 problems, extents drawn from {8, 16, 24, 32}, seed 0xC7C05, one launch."""
+    _run(cuda, oracle, _problem_set(0xC7C05, 4096, [8, 16, 24, 32]), code)
 
 
 @pytest.mark.parametrize("code", [0, 1])

@@ -42,6 +42,8 @@ CASES = [
     ("nt_kmajor_kmajor", "ak,bk->ab", dict(a=700, b=900, k=96), "f64"),
     ("tn_outer_outer", "ka,kb->ab", dict(a=2048, b=1536, k=40), "f64"),
     ("tn_outer_outer_k64", "ka,kb->ab", dict(a=2050, b=1534, k=64), "f64"),
+    ("tn_outer_outer_k80_five_k_tiles_of_16", "ka,kb->ab", dict(a=2050, b=1534, k=80), "f64"),
+    ("tn_outer_outer_k112_many_items", "ka,kb->ab", dict(a=4100, b=3002, k=112), "f64"),
     ("tt_outer_kmajor", "ka,bk->ab", dict(a=520, b=260, k=130), "f64"),
     ("tt_outer_kmajor_k128", "ka,bk->ab", dict(a=520, b=262, k=128), "f64"),
     ("many_items_kmajor_kmajor_k96", "ak,bk->ab", dict(a=4100, b=3000, k=96), "f64"),
@@ -62,18 +64,18 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("dma", [1, 0], ids=["lds_dma", "register_staged"])
+@pytest.mark.parametrize("dma,alpha", [(1, 1.0), (1, 1.25), (0, 1.25)], ids=["lds_dma", "lds_dma_scaled", "register_staged"])
 @pytest.mark.parametrize("name,spec,ext,dtype", CASES, ids=[c[0] for c in CASES])
-def test_persistent_kernel_against_oracle(cuda, oracle, forced_stream, name, spec, ext, dtype, dma):
-    """fp64 has two forms of the persistent kernel (operands staged by LDS-DMA, or through registers as
-    in fp32); fp32 has the second only."""
+def test_persistent_kernel_against_oracle(cuda, oracle, forced_stream, name, spec, ext, dtype, dma, alpha):
+    """fp64 has two forms of the persistent kernel (operands staged by LDS-DMA, with and without the
+    multiplication by alpha, or through registers as in fp32); fp32 has the last only."""
     if dtype == "f32" and dma:
         pytest.skip("fp32 has no LDS-DMA form")
     ctc_amd.set_option("stream_f64_dma", dma)
     try:
-        # the LDS-DMA form takes alpha == 1 and K a multiple of 32 only: other cases fall back to the
+        # the LDS-DMA form takes K a multiple of its K-tile only: other cases fall back to the
         # register-staged form, which the test then simply runs twice
-        _run_case(cuda, oracle, spec, ext, dtype, alpha=1.0 if dma else 1.25)
+        _run_case(cuda, oracle, spec, ext, dtype, alpha=alpha)
     finally:
         ctc_amd.set_option("stream_f64_dma", 1)
 
@@ -92,8 +94,10 @@ def test_which_kernel_runs(cuda, oracle):
     ctc_amd.set_option("stream_mode", 2)
     try:
         assert delta(run("ak,kb->ab", dict(a=4096, b=4096, k=64))) == (0, 0, 1)
-        assert delta(run("ak,kb->ab", dict(a=4096, b=4096, k=64), alpha=2.0)) == (0, 1, 0)      # alpha != 1
+        assert delta(run("ak,kb->ab", dict(a=4096, b=4096, k=64), alpha=2.0)) == (0, 0, 1)      # alpha != 1: its own instantiation
         assert delta(run("ak,kb->ab", dict(a=4096, b=4096, k=80))) == (0, 1, 0)                 # K not a multiple of 32
+        assert delta(run("ka,kb->ab", dict(a=4096, b=4096, k=80))) == (0, 0, 1)                 # outer-major pair: K-tiles of 16
+        assert delta(run("ka,kb->ab", dict(a=4096, b=4096, k=72))) == (0, 1, 0)
         assert delta(run("aef,feb->ab", dict(a=4096, b=4096, e=8, f=8))) == (0, 1, 0)           # k offsets not one stride
         assert delta(run("ak,kb->ab", dict(a=4096, b=4096, k=64), beta=1.0)) == (1, 0, 0)       # beta != 0
         assert delta(run("ak,kb->ab", dict(a=4096, b=4096, k=32))) == (1, 0, 0)                 # one K-tile only
@@ -103,6 +107,32 @@ def test_which_kernel_runs(cuda, oracle):
         assert delta(run("ak,kb->ab", dict(a=4096, b=4096, k=64))) == (1, 0, 0)
     finally:
         ctc_amd.set_option("stream_mode", 0)
+
+
+def test_automatic_routing_of_short_k(cuda):
+    """Automatic mode, a C of 4096 tiles of 128 x 128: fp64 takes the persistent kernel only in its LDS-DMA
+    form; what that form cannot run goes to the one-tile-per-workgroup kernels, never to the (slower)
+    register-staged persistent form.  fp32 has the register-staged form only and takes it."""
+    names = ("launches_classic", "launches_dma_gemm", "launches_stream", "launches_stream_f64_dma")
+
+    def delta(fn):
+        before = [ctc_amd.get_option(n) for n in names]
+        fn()
+        d = [ctc_amd.get_option(n) - b for n, b in zip(names, before)]
+        return (d[0] + d[1], d[2], d[3])
+    x = torch.zeros(8192 * 128, dtype=torch.float64, device=cuda)
+    c = torch.zeros(8192 * 8192, dtype=torch.float64, device=cuda)
+    run = lambda spec, ext, dt="f64", **kw: lambda: ctc_amd.Plan(spec, ext, dt).execute(x, x, c, **kw)  # noqa: E731
+    assert ctc_amd.get_option("stream_mode") == 0
+    assert delta(run("ak,kb->ab", dict(a=8192, b=8192, k=64))) == (0, 0, 1)
+    assert delta(run("ak,kb->ab", dict(a=8192, b=8192, k=64), alpha=1.25)) == (0, 0, 1)
+    assert delta(run("ak,kb->ab", dict(a=8192, b=8192, k=40))) == (1, 0, 0)                  # K = 40: no whole K-tiles
+    assert delta(run("ka,kb->ab", dict(a=8192, b=8192, k=40))) == (1, 0, 0)
+    assert delta(run("ka,kb->ab", dict(a=8192, b=8192, k=80))) == (0, 0, 1)                  # K-tiles of 16
+    assert delta(run("ak,kb->ab", dict(a=8192, b=8192, k=80))) == (1, 0, 0)                  # K-tiles of 32 only
+    assert delta(run("aef,feb->ab", dict(a=8192, b=8192, e=8, f=8))) == (1, 0, 0)             # k offsets not one stride
+    assert delta(run("ak,kb->ab", dict(a=8192, b=8192, k=256))) == (1, 0, 0)                 # K above the cut
+    assert delta(run("ak,kb->ab", dict(a=8192, b=8192, k=64), "f32")) == (0, 1, 0)
 
 
 def _run_case(cuda, oracle, spec, ext, dtype, alpha=1.25):
