@@ -120,7 +120,7 @@ def test_automatic_routing_of_short_k(cuda):
         fn()
         d = [ctc_amd.get_option(n) - b for n, b in zip(names, before)]
         return (d[0] + d[1], d[2], d[3])
-    x = torch.zeros(8192 * 128, dtype=torch.float64, device=cuda)
+    x = torch.zeros(8192 * 256, dtype=torch.float64, device=cuda)  # the largest operand below: 8192 x 256
     c = torch.zeros(8192 * 8192, dtype=torch.float64, device=cuda)
     run = lambda spec, ext, dt="f64", **kw: lambda: ctc_amd.Plan(spec, ext, dt).execute(x, x, c, **kw)  # noqa: E731
     assert ctc_amd.get_option("stream_mode") == 0
