@@ -20,7 +20,7 @@ SYMBOLS = (
 )
 # contracted-mode sharding over RCCL (also declared in include/ctc_tc.h)
 SHARDED_SYMBOLS = (
-    "ctc_tc_comm_unique_id", "ctc_tc_comm_init_rank", "ctc_tc_comm_init_all", "ctc_tc_comm_destroy",
+    "ctc_tc_comm_unique_id", "ctc_tc_comm_init_rank", "ctc_tc_comm_init_all", "ctc_tc_comm_destroy", "ctc_tc_comm_abort",
     "ctc_tc_sharded_create", "ctc_tc_sharded_destroy", "ctc_tc_sharded_get", "ctc_tc_sharded_chunk_plan",
     "ctc_tc_sharded_prepare", "ctc_tc_sharded_execute",
 )
@@ -115,6 +115,8 @@ def load():
     L.ctc_tc_comm_init_all.argtypes = [ctypes.POINTER(vp), ctypes.c_int, vp]
     L.ctc_tc_comm_destroy.restype = ctypes.c_int
     L.ctc_tc_comm_destroy.argtypes = [vp]
+    L.ctc_tc_comm_abort.restype = ctypes.c_int
+    L.ctc_tc_comm_abort.argtypes = [vp]
     L.ctc_tc_sharded_create.restype = ctypes.c_int
     L.ctc_tc_sharded_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, vp, ctypes.c_int, ctypes.c_char,
                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]

@@ -432,7 +432,9 @@ namespace {
 // nothing has to be cleared between calls).  `scratch` is a host-side stand-in for the symbol: the
 // device address is looked up once per device (scratch_setup, reached from ctc_tc_plan_prepare) and only
 // that address is ever handed to a kernel.
-constexpr size_t kScratchBytes = size_t(128) << 20;
+// 64 MiB: one 128 x 128 fp64 slab per workgroup slot of the chip (512), which is the most a schedule of the
+// LDS-DMA kernel ever asks for; schedules of the other kernels that need more are refused.
+constexpr size_t kScratchBytes = size_t(64) << 20;
 constexpr int kMaxDevices = 64;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 std::atomic<void *> g_scratch_ptr[kMaxDevices];  // written once per device (scratch_setup), read by every execution
@@ -525,6 +527,14 @@ int ctc_tc_set_option(const char *name, int64_t value)
         g_stream_max_k.store(value);
         return CTC_TC_OK;
     }
+    if (n == "stream_k") {
+        ctc::dma_gemm_set_stream_k((int)value);
+        return CTC_TC_OK;
+    }
+    if (n == "stream_k_group") {
+        ctc::dma_gemm_set_stream_k_group((int)value);
+        return CTC_TC_OK;
+    }
     return fail(CTC_TC_EINVAL, "unknown option '" + n + "'");
 }
 
@@ -536,6 +546,8 @@ int64_t ctc_tc_get_option(const char *name)
     if (n == "stream_max_k") return g_stream_max_k.load();
     if (n == "stream_f64_dma") return g_stream_f64_dma.load();
     if (n == "dma_gemm") return g_dma_gemm.load();
+    if (n == "stream_k") return ctc::dma_gemm_get_stream_k();
+    if (n == "stream_k_group") return ctc::dma_gemm_get_stream_k_group();
     if (n == "launches_dma_gemm") return g_launches_dma_gemm.load();
     if (n == "launches_bf16_ring") return ctc::bf16_ring_launches();
     if (n == "launches_classic") return g_launches_classic.load();
@@ -638,7 +650,7 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
         if (e != hipSuccess) return fail_hip(e, "contraction schedule");
         v = {sch.nbm, sch.nbn, sch.dp_tiles, sch.tail_tiles, sch.split, (int64_t)sch.ws_bytes,
              (int64_t)ctc::dma_gemm_kind(p.dtype, p.layout_a, p.layout_b, p.tile.bm, p.tile.bn, g),
-             (int64_t)worst_splitk_bytes(p)};
+             (int64_t)worst_splitk_bytes(p), sch.sk_units};
         break;
     }
     default: return fail(CTC_TC_EINVAL, "unknown query");

@@ -20,11 +20,14 @@
 // instead of '->' inside plugin templates.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -248,8 +251,37 @@ int main(int argc, char **argv)
         if (contracted && !use_rccl) partials.resize((size_t)ngpu);
         std::vector<std::string> errors((size_t)ngpu);
         std::vector<double> rank_ms((size_t)ngpu, 0.0);
+        // Collectives need every rank: a rank that fails while setting up must not leave its peers waiting
+        // inside one for ever.  Every worker finishes its fallible set-up (allocations, uploads, plans, tables),
+        // then all meet here; the collectives are entered only if every rank got this far.  A rank that fails
+        // later, between collectives, aborts every communicator so that its peers' calls return with an error.
+        std::mutex gate_mu;
+        std::condition_variable gate_cv;
+        int gate_arrived = 0;
+        bool gate_all_ok = true;
+        auto meet = [&](bool ok) {
+            std::unique_lock<std::mutex> lock(gate_mu);
+            gate_all_ok = gate_all_ok && ok;
+            if (++gate_arrived == ngpu) gate_cv.notify_all();
+            else gate_cv.wait(lock, [&] { return gate_arrived == ngpu; });
+            return gate_all_ok;
+        };
+        std::atomic<bool> aborted{false};
+        auto abort_collectives = [&]() {
+            if (use_rccl && !aborted.exchange(true))
+                for (void *c : comms) (void)ctc_tc_comm_abort(c);  // frees them as well
+        };
         auto worker = [&](int r) {
-            auto fail = [&](const std::string &m) { errors[(size_t)r] = m; };
+            bool met = !contracted;  // only the contracted path has a meeting point
+            auto fail = [&](const std::string &m) {
+                errors[(size_t)r] = m;
+                if (!met) {
+                    met = true;
+                    (void)meet(false);
+                } else if (contracted) {
+                    abort_collectives();
+                }
+            };
             if (hipSetDevice(r % ndev) != hipSuccess) return fail("hipSetDevice");
             // slab [r cnt, (r+1) cnt) of `mode` of a packed operand -> packed device buffer
             auto upload = [&](const std::vector<char> &host, const char *gen, size_t n_full, const Geo &g, void **dev) -> bool {
@@ -287,6 +319,11 @@ int main(int argc, char **argv)
                 const size_t n_ws = (size_t)ctc_tc_sharded_get(sh, CTC_TC_SQ_WORKSPACE_ELEMS, 0);
                 if (hipMalloc(&dC, n_out * es) != hipSuccess || (n_ws && hipMalloc(&dW, n_ws * es) != hipSuccess)) return fail("hipMalloc");
                 if (ctc_tc_sharded_prepare(sh) < 0) return fail(std::string("prepare: ") + ctc_tc_last_error());
+                met = true;
+                if (!meet(true)) {
+                    errors[(size_t)r] = "not started: another rank failed during set-up";
+                    return;
+                }
                 for (int it = 0; it < iters + 1; ++it) {  // the last execution is the one whose result is kept
                     if (it == 0 && iters > 0) (void)hipEventRecord(e0, nullptr);
                     if (it == iters && iters > 0) (void)hipEventRecord(e1, nullptr);
@@ -346,9 +383,19 @@ int main(int argc, char **argv)
         std::vector<std::thread> threads;
         for (int r = 0; r < ngpu; ++r) threads.emplace_back(worker, r);
         for (auto &th : threads) th.join();
-        for (int r = 0; r < ngpu; ++r)
-            if (!errors[(size_t)r].empty()) die("rank " + std::to_string(r) + ": " + errors[(size_t)r]);
-        for (void *c : comms) ctc_tc_comm_destroy(c);
+        {
+            // report the rank that failed by itself before the ranks that merely did not start
+            std::string first;
+            for (int r = 0; r < ngpu; ++r)
+                if (!errors[(size_t)r].empty() && (first.empty() || first.find("not started") != std::string::npos))
+                    first = "rank " + std::to_string(r) + ": " + errors[(size_t)r];
+            if (!first.empty()) {
+                abort_collectives();
+                die(first);
+            }
+        }
+        if (!aborted.load())
+            for (void *c : comms) ctc_tc_comm_destroy(c);
         if (contracted && !use_rccl) {
             // ranks shared devices: sum the partial results here, in rank order
             auto sum = [&](auto *dst, size_t n) {

@@ -107,12 +107,12 @@ constexpr int64_t kNoOffset = INT64_MIN;
 
 // Epilogue of a BM x BN tile held as TM x TN 16 x 16 accumulators per wave (wave origin wm0, wn0; s_coff:
 // the tile's BM row offsets, then its BN column offsets, kNoOffset outside C).  partial: the workgroup
-// multiplied K chunk `chunk` of split tile `sid`; its raw sums go to the workspace.  Every lane of the
-// wave must call.
+// multiplied a part of a tile's K range; its raw sums go to slab `slab_index` of the workspace.  Every
+// lane of the wave must call.
 template <typename T, int BM, int BN, int TM, int TN>
-__device__ __forceinline__ void store_tile(const GemmParams &p, typename Traits<T>::acc_t (&acc)[TM][TN],
-                                           const int64_t *s_coff, T *C, int wm0, int wn0, int lane, bool partial,
-                                           int sid, int chunk)
+__device__ __forceinline__ void store_tile_slab(const GemmParams &p, typename Traits<T>::acc_t (&acc)[TM][TN],
+                                                const int64_t *s_coff, T *C, int wm0, int wn0, int lane, bool partial,
+                                                int64_t slab_index)
 {
     typedef Traits<T> Tr;
     const int frow = lane & 15;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, typename Traits<
     // beta test is hoisted so the common beta == 0 path is a straight run of stores.
     if (partial) {
         // raw accumulators of this K chunk: tile-shaped slab [BM][BN] in the workspace
-        T *slab = static_cast<T *>(p.ws) + ((int64_t)(sid - p.dp_tiles) * p.split + chunk) * (BM * BN);
+        T *slab = static_cast<T *>(p.ws) + slab_index * (BM * BN);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -204,6 +204,15 @@ __device__ __forceinline__ void store_tile(const GemmParams &p, typename Traits<
         if (beta == (T)0) store_rows(std::false_type());
         else store_rows(std::true_type());
     }
+}
+
+// The same for K chunk `chunk` of split tile `sid` (every tile from dp_tiles on is cut into p.split chunks).
+template <typename T, int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void store_tile(const GemmParams &p, typename Traits<T>::acc_t (&acc)[TM][TN],
+                                           const int64_t *s_coff, T *C, int wm0, int wn0, int lane, bool partial,
+                                           int sid, int chunk)
+{
+    store_tile_slab<T, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, (int64_t)(sid - p.dp_tiles) * p.split + chunk);
 }
 
 // Stages a BR x BK operand tile: global -> registers -> LDS.

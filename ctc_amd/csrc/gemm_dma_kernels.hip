@@ -61,6 +61,23 @@ template <typename T> __device__ __forceinline__ void lds_wait8(T &a0, T &a1, T 
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
 }
 
+// Stream-K shares (GemmParams::sk_units, sk_group): the launch's last tiles are taken g = sk_group at a time
+// (consecutive tile ids: neighbours that share operand panels); the W = groups x nk K-tile iterations of these
+// groups of tiles, in order, are cut into units / g runs, and the g workgroups of run u work run u off together,
+// workgroup j on tile j of the group the run is passing through: run u is [sk_unit_start(u), sk_unit_start(u + 1)).  A cut that would
+// fall within kSkSnap K-tiles of a tile's first or last iteration is moved onto the tile boundary (no pieces
+// of a few K-tiles, each of which would cost a prologue, a slab and a share of the fix-up pass).  Kernel,
+// fix-up kernel and host call this one function.
+constexpr int kSkSnap = 8;
+__host__ __device__ inline int64_t sk_unit_start(int64_t u, int64_t W, int64_t units, int64_t nk)
+{
+    int64_t s = u * W / units;
+    const int64_t r = s % nk;
+    if (r < kSkSnap) s -= r;
+    else if (nk - r < kSkSnap) s += nk - r;
+    return s;
+}
+
 // What a lane fetches for its NI DMA instructions per K-tile of one operand, and where a lane's MFMA
 // fragments sit in the operand's image.
 template <typename T, int LAY, int RB> struct Operand {
@@ -184,25 +201,71 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     const unsigned long long ck_core0 = __builtin_readcyclecounter(), ck_real0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    // A launch may have fewer workgroups than items (whole tiles, then the K chunks of the last round's
-    // tiles): workgroup b then takes items b, b + gridDim.x, ... (gridDim.x a multiple of 8, so an item's
-    // XCD is the workgroup's).
-    const int n_items = p.dp_tiles + (p.split > 1 ? (p.nbm * p.nbn - p.dp_tiles) * p.split : 0);
-    for (int bid = blockIdx.x; bid < n_items; bid += gridDim.x) {
-    // item -> tile, as in gemm_kernel: XCD-contiguous runs of tile ids, groups of tile rows, the tiles of
-    // the last round cut along K
-    int sid, chunk = 0;
-    bool partial = false;
+    // RAGGED: the k tables are affine inside runs of p.k_run >= BK contracted elements only, and a run is no
+    // multiple of the K-tile.  A run is then cut into ceil(run / BK) tiles whose last one is the LAST BK elements
+    // of the run: it overlaps its predecessor by `skip_tail` elements, which are zeroed in the fragments of both
+    // operands (in registers, behind the wait that delivers them; k-steps that are overlap entirely are not
+    // multiplied at all), so every tile is one affine window of BK elements inside the operands.
+    const int run = RAGGED ? (int)p.k_run : BK;
+    const int tiles_per_run = (run + BK - 1) / BK;
+    const int skip_tail = tiles_per_run * BK - run;
+    const int nk_total = RAGGED ? (int)(p.K / run) * tiles_per_run : (int)(p.K / BK);
+
+    // A launch may have fewer workgroups than items: workgroup b then takes items b, b + gridDim.x, ...
+    // (gridDim.x a multiple of 8, so an item's XCD is the workgroup's).  Items: the tiles that run whole, then
+    // either the K chunks of the remaining tiles (p.split of equal length per tile) or p.sk_units shares of
+    // the remaining tiles' K-tile iterations (a share is worked off piece by piece: the rest of a tile,
+    // whole tiles, the beginning of a tile).
+    const int tail_tiles = p.nbm * p.nbn - p.dp_tiles;
+    const int n_items = p.dp_tiles + (p.sk_units > 0 ? p.sk_units : (p.split > 1 ? tail_tiles * p.split : 0));
+    const int sk_runs = p.sk_units / p.sk_group;  // runs of K-tile iterations, each worked off by sk_group workgroups
+    const int64_t sk_total = (int64_t)((tail_tiles + p.sk_group - 1) / p.sk_group) * nk_total;
+    int64_t sk_it = 0, sk_end = 0;  // what is left of the share being worked off
+    int sk_unit = 0;
+    for (int bid = blockIdx.x;;) {
+    // item -> tile, as in gemm_kernel: XCD-contiguous runs of tile ids, groups of tile rows
+    int sid, kt_first = 0, kt_last = nk_total;
+    int64_t slab = 0;
+    bool partial = false;  // raw sums to slab `slab` of the workspace instead of C
     {
-        if (bid < p.dp_tiles) {
-            const int nblk = p.dp_tiles;
-            const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-            sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        } else {
-            const int item = bid - p.dp_tiles;
-            sid = p.dp_tiles + item / p.split;
-            chunk = item % p.split;
-            partial = true;
+        auto xcd_run = [](int item, int nblk) {  // XCD-contiguous renumbering of nblk items
+            const int xcd = item & 7, q = nblk >> 3, r = nblk & 7;
+            return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (item >> 3);
+        };
+        bool from_share = sk_it < sk_end;
+        if (!from_share) {
+            if (bid >= n_items) break;
+            const int item = bid;
+            bid += gridDim.x;
+            if (item < p.dp_tiles) {
+                sid = xcd_run(item, p.dp_tiles);
+            } else if (p.sk_units > 0) {
+                sk_unit = xcd_run(item - p.dp_tiles, p.sk_units);
+                sk_it = sk_unit_start(sk_unit / p.sk_group, sk_total, sk_runs, nk_total);
+                sk_end = sk_unit_start(sk_unit / p.sk_group + 1, sk_total, sk_runs, nk_total);
+                if (sk_it >= sk_end) continue;
+                from_share = true;
+            } else {
+                const int chunk_item = item - p.dp_tiles, chunk = chunk_item % p.split;
+                sid = p.dp_tiles + chunk_item / p.split;
+                kt_first = (int)((int64_t)chunk * nk_total / p.split);
+                kt_last = (int)((int64_t)(chunk + 1) * nk_total / p.split);
+                slab = chunk_item;
+                partial = true;
+            }
+        }
+        if (from_share) {
+            // the next piece: from sk_it to the end of its tile or of the share.  A piece that starts a tile
+            // goes to C like a whole tile (alpha, beta); one that starts inside a tile - only a share's first
+            // piece can - leaves its raw sums in the share's slab, and the fix-up pass adds them to C.
+            const int tile_rel = (int)(sk_it / nk_total) * p.sk_group + sk_unit % p.sk_group;
+            sid = p.dp_tiles + tile_rel;
+            kt_first = (int)(sk_it % nk_total);
+            kt_last = (int)(sk_end - sk_it < (int64_t)(nk_total - kt_first) ? kt_first + (sk_end - sk_it) : nk_total);
+            partial = kt_first != 0;
+            slab = sk_unit;
+            sk_it += kt_last - kt_first;
+            if (tile_rel >= tail_tiles) continue;  // the last group of tiles is not full: nothing for this workgroup there
         }
     }
     const int width = p.group * p.nbn;
@@ -218,17 +281,6 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     const char *B = reinterpret_cast<const char *>(static_cast<const T *>(p.B) + p.bat_b[bz]);
     T *C = static_cast<T *>(p.C) + p.bat_c[bz];
 
-    // RAGGED: the k tables are affine inside runs of p.k_run >= BK contracted elements only, and a run is no
-    // multiple of the K-tile.  A run is then cut into ceil(run / BK) tiles whose last one is the LAST BK elements
-    // of the run: it overlaps its predecessor by `skip_tail` elements, which are zeroed in the fragments of both
-    // operands (in registers, behind the wait that delivers them; k-steps that are overlap entirely are not
-    // multiplied at all), so every tile is one affine window of BK elements inside the operands.
-    const int run = RAGGED ? (int)p.k_run : BK;
-    const int tiles_per_run = (run + BK - 1) / BK;
-    const int skip_tail = tiles_per_run * BK - run;
-    const int nk_total = RAGGED ? (int)(p.K / run) * tiles_per_run : (int)(p.K / BK);
-    const int kt_first = partial ? (int)((int64_t)chunk * nk_total / p.split) : 0;
-    const int kt_last = partial ? (int)((int64_t)(chunk + 1) * nk_total / p.split) : nk_total;
     const int nk = kt_last - kt_first;
     // RAGGED: run and tile inside the run of the chunk's first tile, of the tile requested next, and the tile
     // inside its run of the tile multiplied next
@@ -419,7 +471,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     frags_wait(I0());
     frags_wait(I1());
 
-    store_tile<T, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, sid, chunk);
+    store_tile_slab<T, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, slab);
     __syncthreads();  // s_coff and the stages are the next item's
     }
 #ifdef CTC_CLOCK
@@ -428,6 +480,55 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
         printf("[clock] block %d: %llu core ticks in %llu x 10 ns -> %.3f GHz\n", (int)blockIdx.x, dc, dr, (double)dc / (10.0 * (double)dr));
     }
 #endif
+}
+
+// Fix-up pass of a launch with stream-K shares: every tile of the shared-out part that a share boundary cuts
+// has its first piece in C already (alpha and beta applied) and the raw sums of its other pieces in the slabs
+// of the shares that begin inside it; they are added in share order: C += alpha * (slab + slab + ...).
+// One workgroup per 16 rows of a tile; tiles no boundary cuts have nothing to add.
+template <typename T> __global__ void __launch_bounds__(256) sk_fixup_kernel(const GemmParams p, int nk)
+{
+    constexpr int BM = kBM, BN = kBN, ROWS = 16, VPR = BN / 2, RPP = 256 / VPR;
+    const int tile_rel = blockIdx.x / (BM / ROWS);
+    const int rblk = blockIdx.x % (BM / ROWS);
+    const int tail_tiles = p.nbm * p.nbn - p.dp_tiles;
+    const int g = p.sk_group, units = p.sk_units / g;  // runs
+    const int64_t W = (int64_t)((tail_tiles + g - 1) / g) * nk, lo = (int64_t)(tile_rel / g) * nk, hi = lo + nk;
+    // runs that begin strictly inside the tile's group of tiles: [u0, u1); the tile's slabs are those of workgroup
+    // tile_rel % g of each
+    int u0 = (int)(lo * units / W);
+    u0 = u0 > 0 ? u0 - 1 : 0;
+    while (u0 < units && sk_unit_start(u0, W, units, nk) <= lo) ++u0;
+    int u1 = u0;
+    while (u1 < units && sk_unit_start(u1, W, units, nk) < hi) ++u1;
+    if (u0 == u1) return;
+    const int sid = p.dp_tiles + tile_rel;
+    const int width = p.group * p.nbn;
+    const int first_m = (sid / width) * p.group;
+    const int gsz = min(p.nbm - first_m, p.group);
+    const int tm = first_m + (sid % width) % gsz;
+    const int tn = (sid % width) / gsz;
+    const T *ws = static_cast<const T *>(p.ws);
+    T *C = static_cast<T *>(p.C);
+    const T alpha = (T)p.alpha;
+    const int cv = threadIdx.x % VPR;
+    const int64_t n = (int64_t)tn * BN + 2 * cv;
+    const bool ok0 = n < p.N, ok1 = n + 1 < p.N;
+    const int64_t c0 = p.col_c[ok0 ? n : 0], c1 = p.col_c[ok1 ? n + 1 : 0];
+    for (int rr = threadIdx.x / VPR; rr < ROWS; rr += RPP) {
+        const int row = rblk * ROWS + rr;
+        const int64_t m = (int64_t)tm * BM + row;
+        if (m >= p.M) continue;
+        T s0 = 0, s1 = 0;
+        for (int u = u0; u < u1; ++u) {
+            const T *src = ws + ((int64_t)u * g + tile_rel % g) * (BM * BN) + row * BN + 2 * cv;
+            s0 += src[0];
+            s1 += src[1];
+        }
+        const int64_t ro = p.row_c[m];
+        if (ok0) C[ro + c0] += alpha * s0;
+        if (ok1) C[ro + c1] += alpha * s1;
+    }
 }
 
 template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> int resident_slots()
@@ -445,14 +546,19 @@ template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> int residen
     return slots > 0 ? slots : 0;
 }
 
+std::atomic<int> g_sk_group{getenv("CTC_TC_STREAMK_GROUP") ? atoi(getenv("CTC_TC_STREAMK_GROUP")) : 16};  // tiles per group of shares
+std::atomic<int> g_stream_k{getenv("CTC_TC_STREAMK") ? atoi(getenv("CTC_TC_STREAMK")) : 0};  // 0 by cost, 1 never, 2 whenever possible
+
 // Chunk overhead of the split along K, in contracted elements: prologue, raw sums to the workspace, the
 // chunk's share of the fix-up pass; the same 128 as in gemm_kernels.hip.
 constexpr int kMinChunkK = 128;
 
-int best_split(int64_t tail, int slots, int nk, int min_chunk_tiles)
+// f_cap: largest f allowed
+int best_split(int64_t tail, int slots, int nk, int min_chunk_tiles, int f_cap)
 {
     int fmax = nk / min_chunk_tiles;
     if (fmax > 1024) fmax = 1024;
+    if (fmax > f_cap) fmax = f_cap;
     int best_f = 1;
     double best = (double)nk;
     for (int f = 2; f <= fmax; ++f) {
@@ -483,9 +589,41 @@ template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> hipError_t 
     const int nk = RAGGED ? (int)((p.K / p.k_run) * ((p.k_run + BK - 1) / BK)) : (int)(p.K / BK);
     if (!no_split && slots > 0 && p.batch == 1) {
         const int tail = (int)(tiles % slots);
+        const int64_t rounds = tiles / slots;
         if (tail > 0) {
-            const int f = best_split(tail, slots, nk, kMinChunkK / BK);
-            if (f >= 2) {
+            const int ovh = kMinChunkK / BK;  // cost of a piece beside its K-tiles, in K-tile times
+            // (b) stream-K over the last round and the full round before it (so that a share is at least one
+            // tile long and no tile is cut more than once): every workgroup ends at the same time whatever the
+            // tile count is, at the price of up to two more pieces per workgroup, a slab per share and the
+            // fix-up pass.  With fewer tiles than slots the shares are shorter than a tile.
+            const int sk_mode = g_stream_k.load() - 1;  // -1 by cost, 0 never, 1 whenever possible
+            double cost_sk = 1e300;
+            int sk_tiles = 0, sk_units = 0;
+            const int sk_group = g_sk_group.load();
+            if (sk_mode != 0 && nk >= 8 * kSkSnap && slots % sk_group == 0) {
+                sk_tiles = rounds >= 1 ? tail + slots : tail;
+                const int64_t W = (int64_t)((sk_tiles + sk_group - 1) / sk_group) * nk;  // iterations of groups of tiles
+                int runs = slots / sk_group;
+                if (W / runs < 8 * kSkSnap) runs = (int)(W / (8 * kSkSnap));
+                sk_units = runs * sk_group;
+                if (runs >= 2) {
+                    const double share = (double)((W + runs - 1) / runs);
+                    cost_sk = (double)(rounds >= 1 ? rounds - 1 : 0) * nk + share + 1.5 * ovh;
+                }
+            }
+            // (a) the tiles of the last round in f chunks of equal length each (tail x f slabs of workspace; (b)
+            // never needs more than one slab per workgroup slot)
+            const int f = best_split(tail, slots, nk, ovh, 1024);
+            const double cost_split = f >= 2 ? (double)rounds * nk + (double)(((int64_t)tail * f + slots - 1) / slots) * ((double)nk / f + ovh)
+                                             : (double)(rounds + 1) * nk;
+            if (cost_sk < cost_split * (sk_mode == 1 ? 1e9 : 0.995)) {
+                s.tail_tiles = sk_tiles;
+                s.dp_tiles = (int)tiles - sk_tiles;
+                s.split = 1;
+                s.sk_units = sk_units;
+                s.sk_group = sk_group;
+                s.ws_bytes = (size_t)sk_units * kBM * kBN * sizeof(T);
+            } else if (f >= 2) {
                 s.tail_tiles = tail;
                 s.dp_tiles = (int)tiles - tail;
                 s.split = f;
@@ -505,10 +643,12 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     q.nbn = sch.nbn;
     q.dp_tiles = sch.dp_tiles;
     q.split = sch.split;
+    q.sk_units = sch.sk_units;
+    q.sk_group = sch.sk_group > 0 ? sch.sk_group : 1;
     q.ws = ws;
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
-    unsigned items = (unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split);
+    unsigned items = (unsigned)(sch.dp_tiles + (sch.sk_units > 0 ? sch.sk_units : sch.tail_tiles * sch.split));
     // fp64, four rounds of workgroups or more: one workgroup per slot, each walking its items, instead of
     // one workgroup per item (extent 96, 10 rounds: +1 to +3 %; 80 and 88: +0.4 to +0.9 %; two or three
     // rounds: nothing).  Not fp32: there it loses (extent 96: 152.6 -> 141.8 TFLOP/s; the workgroups that
@@ -521,7 +661,11 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     }
     dim3 grid(items, (unsigned)p.batch, 1);
     hipLaunchKernelGGL((gemm_dma_kernel<T, LA, LB, RB, NSUB, RAGGED>), grid, dim3(256), 0, stream, q);
-    if (sch.tail_tiles > 0) {
+    if (sch.sk_units > 0) {
+        constexpr int BK = NSUB * tile_k<T, RB>();
+        const int nk = RAGGED ? (int)((p.K / p.k_run) * ((p.k_run + BK - 1) / BK)) : (int)(p.K / BK);
+        hipLaunchKernelGGL((sk_fixup_kernel<T>), dim3((unsigned)(sch.tail_tiles * (kBM / 16))), dim3(256), 0, stream, q, nk);
+    } else if (sch.tail_tiles > 0) {
         hipError_t e = launch_splitk_fixup_128(sizeof(T) == 8 ? 0 : 1, q, sch.tail_tiles, stream);
         if (e != hipSuccess) return e;
     }
@@ -602,6 +746,11 @@ bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, c
 {
     return dma_gemm_geometry(dtype, layout_a, layout_b, bm, bn, p) != 0;
 }
+
+void dma_gemm_set_stream_k(int mode) { g_stream_k.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
+int dma_gemm_get_stream_k() { return g_stream_k.load(); }
+void dma_gemm_set_stream_k_group(int g) { g_sk_group.store(g < 1 ? 1 : (g > 64 ? 64 : g)); }
+int dma_gemm_get_stream_k_group() { return g_sk_group.load(); }
 
 int dma_gemm_kind(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)
 {

@@ -456,6 +456,11 @@ __global__ void __launch_bounds__(256, Geom<BK>::kTwoPerCu ? 2 : 1) gemm_stream_
                 CTC_SX_STAMP(st_t1);
 #ifdef CTC_SX_NOWAITV  // diagnostic builds (wrong results): tools/build_variant.sh
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#elif defined(CTC_SX_A_ONCE)
+                // diagnostic build (wrong results): the A tile is fetched for a workgroup's first item only, as
+                // if it stayed resident in LDS - what the kernel gains when two thirds of its L2 -> LDS bytes go
+                if (X == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA + (FULL_T && VAR < STORE_TILES ? STORES_AHEAD : 0)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(SB::NI + (FULL_T && VAR < STORE_TILES ? STORES_AHEAD : 0)) : "memory");
 #else
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA + (FULL_T && VAR < STORE_TILES ? STORES_AHEAD : 0)) : "memory");
 #endif
@@ -491,7 +496,11 @@ __global__ void __launch_bounds__(256, Geom<BK>::kTwoPerCu ? 2 : 1) gemm_stream_
                 static_for<0, NDMA>([&](auto u_t) {
                     constexpr int u = decltype(u_t)::value;
                     if (idx == DMA_FIRST + DMA_STEP * u) {
+#ifdef CTC_SX_A_ONCE
+                        if constexpr (u < SA::NI) { if (X == 0) sa.template issue<u>(kofs_a, ld); }
+#else
                         if constexpr (u < SA::NI) sa.template issue<u>(kofs_a, ld);
+#endif
                         else sb.template issue<u - SA::NI>(kofs_b, ld + kABytes);
                     }
                 });

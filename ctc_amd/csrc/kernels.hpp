@@ -31,6 +31,14 @@ struct GemmParams {
     // schedule (filled by launch_gemm): tiles [0, dp_tiles) run whole, every later tile is cut
     // into `split` K chunks whose raw accumulators go to `ws`
     int dp_tiles = 0, split = 1;
+    // sk_units > 0 (LDS-DMA kernel only, instead of `split`): the K-tile iterations of the tiles from dp_tiles
+    // on, taken as ONE sequence (tile after tile, K-tile after K-tile), are dealt out to sk_units workgroups in
+    // equal contiguous shares; a share's pieces of tiles go to C when they start a tile and to slab `unit` of
+    // `ws` otherwise (see sk_unit_start in gemm_dma_kernels.hip)
+    // sk_group: the shares are formed over GROUPS of that many consecutive tiles; the sk_group workgroups of a
+    // group of units walk the same K-tile range of their sk_group tiles together, so that they keep sharing
+    // operand panels in the L2 as whole tiles of a round do (sk_units is a multiple of it)
+    int sk_units = 0, sk_group = 1;
     void *ws = nullptr;
     int c_vec = 1;  // > 1: C may be stored in 16-byte vectors of that many elements along N
     int c_stream = 0;  // 1: C is larger than the Infinity Cache: store it with the non-temporal hint
@@ -50,6 +58,7 @@ struct GemmParams {
 struct GemmSchedule {
     int nbm = 0, nbn = 0;
     int dp_tiles = 0, tail_tiles = 0, split = 1;
+    int sk_units = 0, sk_group = 1;  // > 0: the tail_tiles tiles are shared out in equal runs of K-tiles (GemmParams::sk_units, sk_group)
     size_t ws_bytes = 0;  // workspace the launch needs (0: none)
 };
 
@@ -75,6 +84,13 @@ hipError_t launch_gemm_stream_f64_dma(int layout_a, int layout_b, const GemmPara
 // route to it when dma_gemm_supported says the launch qualifies (vector layouts, k tables affine in aligned
 // groups of at least half a K-tile: k4_affine / k8_affine / k16_affine).
 bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p);
+// how its schedules cut the tiles of the last round: 0 by cost (default), 1 never into stream-K shares, 2 into
+// stream-K shares whenever the launch allows (process-wide, for measurements and tests)
+void dma_gemm_set_stream_k(int mode);
+int dma_gemm_get_stream_k();
+// tiles per group of stream-K shares (GemmParams::sk_group): 1 .. 64, default 16
+void dma_gemm_set_stream_k_group(int g);
+int dma_gemm_get_stream_k_group();
 // which form of it the launch takes: 0 none (the register-staged kernel runs), 1 K-tiles of 64-byte rows,
 // 2 two images of 32-byte rows per stage, 3 one image of 32-byte rows, 4 64-byte rows with ragged K-tiles
 int dma_gemm_kind(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p);

@@ -125,6 +125,14 @@ int ctc_tc_comm_destroy(void *comm)
     return CTC_TC_OK;
 }
 
+int ctc_tc_comm_abort(void *comm)
+{
+    if (!comm) return CTC_TC_OK;
+    ncclResult_t r = ncclCommAbort(static_cast<ncclComm_t>(comm));
+    if (r != ncclSuccess) return fail_nccl(r, "ncclCommAbort");
+    return CTC_TC_OK;
+}
+
 int ctc_tc_sharded_create(const char *spec, int n_ext, const char *mode_names, const int64_t *extents, int dtype,
                           char mode, int rank, int nranks, int nchunks, int reduce, ctc_tc_sharded **out)
 {

@@ -100,7 +100,9 @@ enum ctc_tc_query {
                                   kernel form (0: operands staged through registers; 1-4: staged by LDS-DMA with
                                   K-tiles of 64-byte rows / two images of 32-byte rows / one image of 32-byte rows /
                                   64-byte rows with ragged K-tiles), largest workspace bytes over the launch and its
-                                  fall-backs to element loads for unaligned bases} */
+                                  fall-backs to element loads for unaligned bases, stream-K shares (0: the cut tiles
+                                  are cut into `chunks per such tile` equal chunks; > 0: the K-tile iterations of the
+                                  cut tiles, taken as one sequence, are dealt out in that many equal shares)} */
 };
 
 /* operand layouts reported in CTC_TC_Q_TILE */
@@ -137,7 +139,11 @@ const char *ctc_tc_last_error(void);
  *   "dma_gemm"      1 (default): fp64 / fp32 launches on the 128 x 128 tile whose operands both have a
  *                   16-byte-vector layout and whose k offsets are affine inside every aligned group of 4
  *                   (fp64) or 8 (fp32) contracted indices, K a multiple of that, stage their operands by
- *                   LDS-DMA; 0: always through registers.
+ *                   LDS-DMA; 0: always through registers;
+ *   "stream_k"      how the LDS-DMA kernel's schedule treats a tile count that is no multiple of the chip's
+ *                   workgroup slots: 0 (default) by estimated cost, either the tiles of the last round cut
+ *                   into equal K chunks or the K-tile iterations of the last one to two rounds dealt out in
+ *                   equal shares (stream-K); 1: never shares; 2: shares whenever the launch allows.
  * No reference counterpart.
  */
 int ctc_tc_set_option(const char *name, int64_t value);
@@ -226,6 +232,10 @@ int ctc_tc_comm_unique_id(void *id128);
 int ctc_tc_comm_init_rank(void **comm, int nranks, int rank, const void *id128);
 int ctc_tc_comm_init_all(void **comms, int ndev, const int *devices /* NULL: 0..ndev-1 */);
 int ctc_tc_comm_destroy(void *comm);
+/* Ends a communicator whose collectives can no longer complete (a peer rank failed before entering them):
+ * collectives in flight on it return with an error instead of waiting for ever, and the communicator is
+ * freed (do not destroy it afterwards).  ncclCommAbort. */
+int ctc_tc_comm_abort(void *comm);
 
 /* extents are those of the WHOLE contraction; `mode` must be a contracted mode whose extent is a
  * multiple of nranks; nchunks is the wanted pipeline depth (the largest count <= nchunks that divides
@@ -273,8 +283,12 @@ int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B
  * Same arguments and result as ctc_tc_execute, with these differences:
  *   - it calls no hipMalloc / hipFree and no allocating library routine; the only device memory
  *     beyond A, B and C it touches is a fixed scratch buffer of ctc_tc_noalloc_scratch_bytes()
- *     bytes (128 MiB) that is part of the library's code object, one copy per GPU, held until the
- *     process ends; the split-K partial sums of the last, partly filled round of tiles go there;
+ *     bytes (64 MiB) that is part of the library's code object, one copy per GPU, held until the
+ *     process ends; the split-K partial sums of the last, partly filled round of tiles go there.
+ *     This is what loading libctc_tc.so costs: every process that runs a kernel of the library on a
+ *     GPU holds 64 MiB of that GPU's memory (0.02 % of an MI355X's 288 GB) from the first launch on,
+ *     whether it ever calls this entry point or not.  64 MiB is one 128 x 128 fp64 slab per
+ *     workgroup slot of the chip, the most any schedule of the LDS-DMA GEMM kernel asks for;
  *   - ctc_tc_plan_prepare must have been called for this plan on the current device (it uploads
  *     the tables and resolves the scratch buffer's device address); otherwise CTC_TC_EINVAL;
  *   - a contraction whose schedule needs more scratch than that is rejected with

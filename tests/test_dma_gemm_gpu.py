@@ -153,6 +153,95 @@ def test_dma_gemm_against_oracle_and_register_staged(cuda, oracle, name, spec, e
         ctc_amd.set_option("stream_mode", 0)
 
 
+# Stream-K shares: the K-tile iterations of the last one to two rounds of tiles dealt out in equal runs.  Each
+# case names the schedule it must produce when shares are forced: tiles run whole, tiles shared out.
+STREAM_K_CASES = [
+    # fewer tiles than workgroup slots: shares shorter than a tile, several slabs per tile
+    ("fewer_tiles_than_slots", "ak,kb->ab", dict(a=1024, b=1024, k=4096), "f64"),
+    ("fewer_tiles_ragged_edges", "ka,bk->ab", dict(a=1000, b=900, k=4096), "f64"),
+    # between one and two rounds: every share is longer than a tile, a tile is cut at most once
+    ("one_round_and_a_bit", "ak,kb->ab", dict(a=3072, b=3200, k=1024), "f64"),
+    ("one_round_and_a_bit_ragged_edges", "ak,bk->ab", dict(a=3100, b=3130, k=1000), "f64"),
+    # two full rounds and a bit: the first round runs whole tiles
+    ("two_rounds_and_a_bit", "ka,kb->ab", dict(a=3200, b=5632, k=512), "f64"),
+    # K-tiles that are not 64-byte rows: two images of 32-byte rows (modes of 60: groups of 4), ragged K-tiles (runs of 14)
+    ("rows_of_32_bytes", "aeim,ebmj->abij", dict(a=40, b=40, i=24, j=24, e=60, m=60), "f64"),
+    ("ragged_k_tiles", "aef,feb->ab", dict(a=2560, b=2560, e=40, f=14), "f64"),
+    ("f32_fewer_tiles", "ak,kb->ab", dict(a=1024, b=1152, k=4096), "f32"),
+    ("f32_one_round_and_a_bit", "ka,kb->ab", dict(a=3072, b=3200, k=2048), "f32"),
+]
+
+
+@pytest.mark.parametrize("name,spec,ext,dtype", STREAM_K_CASES, ids=[c[0] for c in STREAM_K_CASES])
+def test_stream_k_shares_against_oracle(cuda, oracle, name, spec, ext, dtype):
+    """Forced stream-K against the oracle (alpha and beta), against the same plan with equal K chunks, and
+    twice in a row bit for bit (the slabs are added in share order: no atomics, nothing depends on timing)."""
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, cuda, dtype)
+    C0 = oracle.fill(n_out, 0xC7C0C, CODE[dtype])
+    plan = ctc_amd.Plan(spec, ext, dtype)
+    ctc_amd.set_option("stream_mode", 1)
+    ctc_amd.set_option("stream_k", 2)
+    try:
+        sch = plan.schedule()
+        assert sch["dma_form"] > 0 and sch["stream_k_shares"] >= 2 and sch["tail_tiles"] > 0, sch
+        assert sch["workspace_bytes"] == sch["stream_k_shares"] * 128 * 128 * (8 if dtype == "f64" else 4), sch
+        dC = torch.from_numpy(C0.copy()).to(cuda)
+        took = _delta(lambda: plan.execute(dA, dB, dC, alpha=0.75, beta=-1.5))
+        assert took == (0, 1, 0, 0), took
+        want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=0.75, beta=-1.5, dtype=CODE[dtype])
+        _check(dC.cpu().numpy(), want, dtype)
+        dC1 = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+        dC2 = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+        plan.execute(dA, dB, dC1)
+        plan.execute(dA, dB, dC2)
+        assert not bool(torch.isnan(dC1).any())
+        assert torch.equal(dC1, dC2)
+        want1 = oracle.contract(spec, ext, A, B, dtype=CODE[dtype])
+        _check(dC1.cpu().numpy(), want1, dtype)
+        ctc_amd.set_option("stream_k", 1)
+        assert plan.schedule()["stream_k_shares"] == 0
+        dC3 = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+        plan.execute(dA, dB, dC3)
+        _check(dC3.cpu().numpy(), want1, dtype)
+    finally:
+        ctc_amd.set_option("stream_k", 0)
+        ctc_amd.set_option("stream_mode", 0)
+
+
+def test_schedule_query_reports_the_kernel_that_runs(cuda):
+    """CTC_TC_Q_SCHEDULE describes the launch ctc_tc_execute makes: the LDS-DMA form for the plan's layouts
+    and k tables, and the workspace that launch uses (checked through the no-allocation entry point, which
+    refuses a launch that needs more than it is given: the fixed buffer must be large enough exactly when the
+    reported bytes say so)."""
+    cases = [
+        ("aeim,ebmj->abij", dict(a=48, b=48, i=48, j=48, e=48, m=48), 1),   # K-tiles of 64-byte rows
+        ("aeim,ebmj->abij", dict(a=44, b=44, i=44, j=44, e=44, m=44), 2),   # modes of 44: groups of 4, two images
+        ("aef,feb->ab", dict(a=2304, b=2304, e=120, f=14), 4),               # runs of 14: ragged K-tiles
+        ("ak,kb->ab", dict(a=2304, b=2304, k=2305), 0),                      # odd K: element loads of A, register-staged
+    ]
+    for spec, ext, form in cases:
+        plan = ctc_amd.Plan(spec, ext, "f64")
+        plan.prepare()
+        sch = plan.schedule()
+        assert sch["dma_form"] == form, (spec, ext, sch)
+        assert sch["workspace_bytes"] > 0 and sch["workspace_bytes_worst"] >= sch["workspace_bytes"], sch
+        fits = sch["workspace_bytes"] <= ctc_amd.noalloc_scratch_bytes()
+        assert fits == (form != 0), sch  # the LDS-DMA kernel's schedules fit by construction; this register-staged one does not
+        ins, outm = spec.split("->")
+        la, lb = ins.split(",")
+        num = lambda t: int(np.prod([ext[c] for c in t]))  # noqa: E731
+        a = torch.zeros(num(la), dtype=torch.float64, device=cuda)
+        b = torch.zeros(num(lb), dtype=torch.float64, device=cuda)
+        c = torch.zeros(num(outm), dtype=torch.float64, device=cuda)
+        if fits:
+            took = _delta(lambda: plan.execute_noalloc(a, b, c))
+            assert took == (0, 1, 0, 0), (spec, took)
+        else:
+            with pytest.raises(ctc_amd.CtcError, match="needs %d bytes" % sch["workspace_bytes"]):
+                plan.execute_noalloc(a, b, c)
+    torch.cuda.synchronize()
+
+
 def test_which_launches_take_the_dma_kernel(cuda):
     x = torch.zeros(4096 * 4096, dtype=torch.float64, device=cuda)
     c = torch.zeros(4096 * 4096, dtype=torch.float64, device=cuda)

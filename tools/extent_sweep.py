@@ -23,6 +23,16 @@ for n in sizes:
     plan = ctc_amd.Plan("aeim,ebmj->abij", ext, dt)
     for _ in range(20 if n < 64 else 3):
         plan.execute(A, B, C)
-    ms = plan.time(A, B, C, warmup=3, iters=20 if n < 64 else 5)
     s = plan.summary()
-    print(json.dumps({"extent": n, "gemm": n * n, "tile": s["tile"], "ms": round(ms, 4), "TFLOP/s": round(plan.flops / ms * 1e-9, 2)}), flush=True)
+    row = {"extent": n, "gemm": n * n, "tile": s["tile"]}
+    # the last round of tiles cut into equal K chunks only, then the schedule chosen by cost (which may deal the
+    # last one to two rounds out in stream-K shares), same process, same buffers
+    for mode, label in ((1, "equal_chunks"), (2, "shares_forced"), (0, "by_cost")):
+        ctc_amd.set_option("stream_k", mode)
+        sch = plan.schedule() if s["kernel"] == "mfma_gemm" else {}
+        ms = plan.time(A, B, C, warmup=3, iters=20 if n < 64 else 5)
+        row[label] = {"ms": round(ms, 4), "TFLOP/s": round(plan.flops / ms * 1e-9, 2), "whole_tiles": sch.get("whole_tiles"),
+                      "tail_tiles": sch.get("tail_tiles"), "split": sch.get("split"), "shares": sch.get("stream_k_shares")}
+    ctc_amd.set_option("stream_k", 0)
+    row["ms"], row["TFLOP/s"] = row["by_cost"]["ms"], row["by_cost"]["TFLOP/s"]
+    print(json.dumps(row), flush=True)
