@@ -17,7 +17,7 @@ def counters(directory, counter):
         for name, cn, value in c.execute("select kernel_name, counter_name, value from counters_collection"):
             if cn != counter:
                 continue
-            if "splitk_fixup" in name:
+            if "splitk_fixup" in name or "sk_fixup" in name:
                 out["fixup"].append(float(value))
             elif "gemm_kernel" in name or "gemm_dma_kernel" in name:
                 out["gemm"].append(float(value))
