@@ -30,8 +30,10 @@ __device__ __forceinline__ void dma16(const void *src, unsigned char *lds_wave_b
 // from assembly (the compiler, given a pointer, adds the two parts on the vector ALU); lds_wave_base is the
 // LDS byte address the wave's 1 KB goes to.  The compiler does not count these transfers in its own
 // s_waitcnt bookkeeping: the caller waits for them explicitly.  M0 is overwritten (it cannot be named as a
-// clobber: the compiler reserves it), so a kernel that uses this must have no other use of M0 alive across
-// the call; the kernels here have none (their only M0 users are these transfers).
+// clobber: the compiler reserves it and only warns), so a kernel that uses this must have no other user of
+// M0: no dma16() above (there the compiler sets M0 and may assume it unchanged across this statement), no
+// dynamically indexed register array (relative moves go through M0).  tests/test_abi.py disassembles the
+// library and checks exactly that for every kernel whose transfers come from here.
 __device__ __forceinline__ void dma16_split(const void *uniform_base, unsigned lane_offset, unsigned lds_wave_base)
 {
     asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
