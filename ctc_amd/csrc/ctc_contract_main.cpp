@@ -283,6 +283,8 @@ int main(int argc, char **argv)
                 }
             };
             if (hipSetDevice(r % ndev) != hipSuccess) return fail("hipSetDevice");
+            // for the tests of the failure path: CTC_CONTRACT_FAIL_RANK=r makes rank r report a set-up failure
+            if (getenv("CTC_CONTRACT_FAIL_RANK") && atoi(getenv("CTC_CONTRACT_FAIL_RANK")) == r) return fail("set-up failure requested by CTC_CONTRACT_FAIL_RANK");
             // slab [r cnt, (r+1) cnt) of `mode` of a packed operand -> packed device buffer
             auto upload = [&](const std::vector<char> &host, const char *gen, size_t n_full, const Geo &g, void **dev) -> bool {
                 const size_t n_loc = g.present ? n_full / (size_t)ngpu : n_full;

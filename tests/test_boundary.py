@@ -206,6 +206,24 @@ def test_several_gpus_with_beta_and_bad_requests(tmp_path, oracle):
         assert run.returncode != 0 and "ctc_contract:" in run.stderr, extra
 
 
+@pytest.mark.gpu
+def test_a_rank_that_fails_during_set_up_does_not_leave_its_peers_waiting(tmp_path, oracle):
+    """Contracted mode over several ranks: the ranks meet after their set-up and enter the collectives (or the
+    host-side sum) only if every one of them got there.  With one rank failing the tool must end at once with
+    that rank's message, not hang in a collective its peer can never complete."""
+    ext = dict(a=40, d=48, c=24, b=32)
+    oracle.fill(40 * 48 * 24, 1).tofile(tmp_path / "A.bin")
+    oracle.fill(48 * 32, 2).tofile(tmp_path / "B.bin")
+    argv = [TOOL, "--spec", "adc,db=abc", "--extents", ",".join("%s=%d" % kv for kv in ext.items()), "--a", str(tmp_path / "A.bin"),
+            "--b", str(tmp_path / "B.bin"), "--out", str(tmp_path / "C.bin"), "--ngpu", "4", "--shard-on", "d"]
+    for failing in ("0", "2"):
+        run = subprocess.run(argv, capture_output=True, text=True, timeout=60, env=dict(os.environ, CTC_CONTRACT_FAIL_RANK=failing))
+        assert run.returncode != 0, run.stdout
+        assert "rank %s: set-up failure requested" % failing in run.stderr, run.stderr
+    run = subprocess.run(argv, capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0, run.stderr
+
+
 def _engine_workflow_dry_run(workflow, params, cwd):
     argv = [ENGINE, eb.ENGINE_ROOT, "--test", "workflow", workflow]
     for k, v in params.items():
