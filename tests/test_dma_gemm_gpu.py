@@ -208,6 +208,60 @@ def test_stream_k_shares_against_oracle(cuda, oracle, name, spec, ext, dtype):
         ctc_amd.set_option("stream_mode", 0)
 
 
+def _random_share_cases(count, seed=20240917):
+    rng = np.random.RandomState(seed)
+    specs = ("ak,kb->ab", "ak,bk->ab", "ka,kb->ab", "ka,bk->ab")
+    out = []
+    for i in range(count):
+        dtype = "f32" if i % 4 == 3 else "f64"
+        unit = 4 if dtype == "f32" else 2  # vector layouts need extents that are multiples of a 16-byte vector
+        m = int(rng.randint(700, 6000)) // unit * unit
+        n = int(rng.randint(700, 6000)) // unit * unit
+        k = int(rng.randint(64, 384)) * 16
+        out.append((specs[i % 4], dict(a=m, b=n, k=k), dtype, (1, 8, 16, 64)[(i // 4) % 4]))
+    return out
+
+
+@pytest.mark.parametrize("spec,ext,dtype,group", _random_share_cases(24),
+                         ids=["%s_%dx%dx%d_%s_g%d" % (c[0].replace(",", "_").replace("->", "_"), c[1]["a"], c[1]["b"], c[1]["k"], c[2], c[3])
+                              for c in _random_share_cases(24)])
+def test_stream_k_shares_random_shapes(cuda, spec, ext, dtype, group):
+    """Seeded random shapes (tile counts from below one round of workgroup slots to several, ragged edges, all
+    four layout pairs, every group size) with stream-K shares forced, against the same plan with equal K chunks:
+    the two schedules add the same products in different orders, so they agree to the parity tolerance; and
+    the shares leave no element of C unwritten."""
+    m, n, k = ext["a"], ext["b"], ext["k"]
+    dA = torch.empty(m * k, dtype=TDT[dtype], device=cuda)
+    dB = torch.empty(n * k, dtype=TDT[dtype], device=cuda)
+    ctc_amd.fill(dA, 0xC7C0A)
+    ctc_amd.fill(dB, 0xC7C0B)
+    plan = ctc_amd.Plan(spec, ext, dtype)
+    if plan.summary()["tile"][:2] != (128, 128):
+        pytest.skip("the planner takes the small tile for this shape")
+    ctc_amd.set_option("stream_mode", 1)
+    try:
+        ctc_amd.set_option("stream_k", 1)
+        want = torch.full((m * n,), float("nan"), dtype=TDT[dtype], device=cuda)
+        plan.execute(dA, dB, want)
+        ctc_amd.set_option("stream_k", 2)
+        ctc_amd.set_option("stream_k_group", group)
+        sch = plan.schedule()
+        got = torch.full((m * n,), float("nan"), dtype=TDT[dtype], device=cuda)
+        took = _delta(lambda: plan.execute(dA, dB, got, alpha=1.0))
+        assert took == (0, 1, 0, 0), took
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(got).any()), sch
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= TOL[dtype] * scale, sch
+        tiles = sch["tile_rows"] * sch["tile_cols"]
+        if tiles % 512:  # the chip's 512 workgroup slots: a ragged tile count is what shares are for
+            assert sch["stream_k_shares"] >= 2, sch
+    finally:
+        ctc_amd.set_option("stream_k", 0)
+        ctc_amd.set_option("stream_k_group", 16)
+        ctc_amd.set_option("stream_mode", 0)
+
+
 def test_schedule_query_reports_the_kernel_that_runs(cuda):
     """CTC_TC_Q_SCHEDULE describes the launch ctc_tc_execute makes: the LDS-DMA form for the plan's layouts
     and k tables, and the workspace that launch uses (checked through the no-allocation entry point, which
