@@ -172,6 +172,10 @@ template <typename T, int LAY, int RB> struct Operand {
 // NSUB: images per operand and stage.  2 (with RB = 32) puts two K-tiles of 32-byte rows, each with its own k
 // offset, into one stage: the K loop then has the shape of the 64-byte geometry (one barrier per 32 MFMAs per
 // wave) for k tables that are affine in groups of half a K-tile only.
+#ifdef CTC_DMA_ROUND_SYNC
+__device__ unsigned g_round_sync[64][8];
+#endif
+
 template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED>
 __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
 {
@@ -473,6 +477,23 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
 
     store_tile_slab<T, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, slab);
     __syncthreads();  // s_coff and the stages are the next item's
+#ifdef CTC_DMA_ROUND_SYNC
+    // Diagnostic build: the workgroups of an XCD that walk their items meet after every round of whole tiles
+    // (bounded wait: a workgroup gives up after about 100 us), so that the eight workgroups sharing a panel
+    // start the next tile together.  p.ka_stride carries the launch's generation number (the kernel does not
+    // use it otherwise): the counters only ever grow.
+    if (gridDim.x < (unsigned)n_items && !partial && sid < p.dp_tiles && sk_it >= sk_end) {
+        if (t == 0) {
+            const int round = (bid - (int)gridDim.x) / (int)gridDim.x;
+            unsigned *ctr = &g_round_sync[round & 63][blockIdx.x & 7];
+            const unsigned target = (unsigned)p.ka_stride * (gridDim.x >> 3);
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int tries = 0; tries < 2000 && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++tries)
+                __builtin_amdgcn_s_sleep(8);
+        }
+        __syncthreads();
+    }
+#endif
     }
 #ifdef CTC_CLOCK
     if (t == 0 && blockIdx.y == 0 && (blockIdx.x == 700 || blockIdx.x == 2500 || blockIdx.x == 4500)) {
@@ -660,6 +681,10 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
         if (slots >= 8 && slots % 8 == 0 && items > slots && (persist == 1 || (sizeof(T) == 8 && items >= 4 * slots))) items = slots;
     }
     dim3 grid(items, (unsigned)p.batch, 1);
+#ifdef CTC_DMA_ROUND_SYNC
+    static std::atomic<int64_t> generation{0};
+    q.ka_stride = generation.fetch_add(1) + 1;
+#endif
     hipLaunchKernelGGL((gemm_dma_kernel<T, LA, LB, RB, NSUB, RAGGED>), grid, dim3(256), 0, stream, q);
     if (sch.sk_units > 0) {
         constexpr int BK = NSUB * tile_k<T, RB>();
