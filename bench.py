@@ -305,7 +305,8 @@ def watchdog(seconds, rank, line, state):
         finish()
         os._exit(EXIT_VARIANTS_TIMED_OUT)
     # rank 0 goes first: a launcher that sees another rank fail ends rank 0 before it has recorded the time-out
-    t = threading.Timer(seconds if rank == 0 else seconds + 5.0, fire)
+    # (rank 0 starts its variants later than the others by the time its CPU baseline takes, some 10 s)
+    t = threading.Timer(seconds if rank == 0 else seconds + 30.0, fire)
     t.daemon = True
     t.start()
     return t
