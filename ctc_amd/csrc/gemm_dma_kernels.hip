@@ -567,7 +567,7 @@ template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> int residen
     return slots > 0 ? slots : 0;
 }
 
-std::atomic<int> g_sk_group{getenv("CTC_TC_STREAMK_GROUP") ? atoi(getenv("CTC_TC_STREAMK_GROUP")) : 16};  // tiles per group of shares
+std::atomic<int> g_sk_group{getenv("CTC_TC_STREAMK_GROUP") ? atoi(getenv("CTC_TC_STREAMK_GROUP")) : 0};  // tiles per group of shares; 0: chosen per launch
 std::atomic<int> g_stream_k{getenv("CTC_TC_STREAMK") ? atoi(getenv("CTC_TC_STREAMK")) : 0};  // 0 by cost, 1 never, 2 whenever possible
 
 // Chunk overhead of the split along K, in contracted elements: prologue, raw sums to the workspace, the
@@ -620,17 +620,31 @@ template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> hipError_t 
             const int sk_mode = g_stream_k.load() - 1;  // -1 by cost, 0 never, 1 whenever possible
             double cost_sk = 1e300;
             int sk_tiles = 0, sk_units = 0;
-            const int sk_group = g_sk_group.load();
-            if (sk_mode != 0 && nk >= 8 * kSkSnap && slots % sk_group == 0) {
+            // groups of 16 tiles (8 tile rows x 2 tile columns) unless groups of 8 leave a share at least 1 %
+            // shorter (the last group of tiles is padded to a whole one; 648 tiles: 41 groups of 16 on 32 runs
+            // against 81 of 8 on 64): the larger group shares more operand panels in the L2, measured worth about
+            // that much.  An explicit "stream_k_group" option fixes the size.
+            int sk_group = 16;
+            if (sk_mode != 0 && nk >= 8 * kSkSnap) {
                 sk_tiles = rounds >= 1 ? tail + slots : tail;
-                const int64_t W = (int64_t)((sk_tiles + sk_group - 1) / sk_group) * nk;  // iterations of groups of tiles
-                int runs = slots / sk_group;
-                if (W / runs < 8 * kSkSnap) runs = (int)(W / (8 * kSkSnap));
-                sk_units = runs * sk_group;
-                if (runs >= 2) {
+                const int forced = g_sk_group.load();
+                double best_share = 1e300;
+                for (int g : {16, 8}) {
+                    if (forced > 0 && g != 16) break;
+                    if (forced > 0) g = forced;
+                    if (slots % g != 0) continue;
+                    const int64_t W = (int64_t)((sk_tiles + g - 1) / g) * nk;  // iterations of groups of tiles
+                    int runs = slots / g;
+                    if (W / runs < 8 * kSkSnap) runs = (int)(W / (8 * kSkSnap));
+                    if (runs < 2) continue;
                     const double share = (double)((W + runs - 1) / runs);
-                    cost_sk = (double)(rounds >= 1 ? rounds - 1 : 0) * nk + share + 1.5 * ovh;
+                    if (share < best_share * (g == 8 ? 0.99 : 1.0)) {
+                        best_share = share;
+                        sk_group = g;
+                        sk_units = runs * g;
+                    }
                 }
+                if (best_share < 1e300) cost_sk = (double)(rounds >= 1 ? rounds - 1 : 0) * nk + best_share + 1.5 * ovh;
             }
             // (a) the tiles of the last round in f chunks of equal length each (tail x f slabs of workspace; (b)
             // never needs more than one slab per workgroup slot)
@@ -774,7 +788,7 @@ bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, c
 
 void dma_gemm_set_stream_k(int mode) { g_stream_k.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
 int dma_gemm_get_stream_k() { return g_stream_k.load(); }
-void dma_gemm_set_stream_k_group(int g) { g_sk_group.store(g < 1 ? 1 : (g > 64 ? 64 : g)); }
+void dma_gemm_set_stream_k_group(int g) { g_sk_group.store(g < 0 ? 0 : (g > 64 ? 64 : g)); }
 int dma_gemm_get_stream_k_group() { return g_sk_group.load(); }
 
 int dma_gemm_kind(int dtype, int layout_a, int layout_b, int bm, int bn, const GemmParams &p)

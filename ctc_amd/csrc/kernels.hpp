@@ -88,7 +88,7 @@ bool dma_gemm_supported(int dtype, int layout_a, int layout_b, int bm, int bn, c
 // stream-K shares whenever the launch allows (process-wide, for measurements and tests)
 void dma_gemm_set_stream_k(int mode);
 int dma_gemm_get_stream_k();
-// tiles per group of stream-K shares (GemmParams::sk_group): 1 .. 64, default 16
+// tiles per group of stream-K shares (GemmParams::sk_group): 1 .. 64; 0 (default): 16, or 8 where that balances better
 void dma_gemm_set_stream_k_group(int g);
 int dma_gemm_get_stream_k_group();
 // which form of it the launch takes: 0 none (the register-staged kernel runs), 1 K-tiles of 64-byte rows,

@@ -143,7 +143,9 @@ const char *ctc_tc_last_error(void);
  *   "stream_k"      how the LDS-DMA kernel's schedule treats a tile count that is no multiple of the chip's
  *                   workgroup slots: 0 (default) by estimated cost, either the tiles of the last round cut
  *                   into equal K chunks or the K-tile iterations of the last one to two rounds dealt out in
- *                   equal shares (stream-K); 1: never shares; 2: shares whenever the launch allows.
+ *                   equal shares (stream-K); 1: never shares; 2: shares whenever the launch allows;
+ *   "stream_k_group" consecutive tiles whose shares walk K together (1 .. 64); 0 (default): 16, or 8 where that
+ *                   leaves less padding.
  * No reference counterpart.
  */
 int ctc_tc_set_option(const char *name, int64_t value);

@@ -258,7 +258,7 @@ def test_stream_k_shares_random_shapes(cuda, spec, ext, dtype, group):
             assert sch["stream_k_shares"] >= 2, sch
     finally:
         ctc_amd.set_option("stream_k", 0)
-        ctc_amd.set_option("stream_k_group", 16)
+        ctc_amd.set_option("stream_k_group", 0)
         ctc_amd.set_option("stream_mode", 0)
 
 
