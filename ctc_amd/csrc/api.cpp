@@ -432,8 +432,9 @@ namespace {
 // nothing has to be cleared between calls).  `scratch` is a host-side stand-in for the symbol: the
 // device address is looked up once per device (scratch_setup, reached from ctc_tc_plan_prepare) and only
 // that address is ever handed to a kernel.
-// 64 MiB: one 128 x 128 fp64 slab per workgroup slot of the chip (512), which is the most a schedule of the
-// LDS-DMA kernel ever asks for; schedules of the other kernels that need more are refused.
+// 64 MiB: one 128 x 128 fp64 slab per workgroup slot of the chip (512): the most a stream-K schedule of the
+// LDS-DMA kernel asks for, and what the extent-96 headline contraction needs; schedules that need more (many
+// equal K chunks) are refused.
 constexpr size_t kScratchBytes = size_t(64) << 20;
 constexpr int kMaxDevices = 64;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];

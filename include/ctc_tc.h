@@ -290,7 +290,8 @@ int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B
  *     This is what loading libctc_tc.so costs: every process that runs a kernel of the library on a
  *     GPU holds 64 MiB of that GPU's memory (0.02 % of an MI355X's 288 GB) from the first launch on,
  *     whether it ever calls this entry point or not.  64 MiB is one 128 x 128 fp64 slab per
- *     workgroup slot of the chip, the most any schedule of the LDS-DMA GEMM kernel asks for;
+ *     workgroup slot of the chip: what a stream-K schedule of the LDS-DMA GEMM kernel asks for at most
+ *     (schedules that cut the last round of tiles into equal K chunks can ask for more);
  *   - ctc_tc_plan_prepare must have been called for this plan on the current device (it uploads
  *     the tables and resolves the scratch buffer's device address); otherwise CTC_TC_EINVAL;
  *   - a contraction whose schedule needs more scratch than that is rejected with
