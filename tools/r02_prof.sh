@@ -1,4 +1,4 @@
-# Round-2 evidence in one GPU call: the whole -m gpu suite, then kernel-trace statistics of the headline
+# in one GPU call: the whole -m gpu suite, then kernel-trace statistics of the headline
 # bench and of the secondary measurements, then counter passes over the short-K slab (persistent kernel).
 # Results under gpurun_out/r02_*; the summaries worth keeping are copied into profiles/ by hand.
 set -e

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 GPU run 1: full GPU test suite, the no-alloc WIP test, bench, and the one-workgroup-per-CU probe
+# full GPU test suite, the no-alloc WIP test, bench, and the one-workgroup-per-CU probe
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > gpurun_out/r1_pytest.log 2>&1

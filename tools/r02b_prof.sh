@@ -1,4 +1,4 @@
-# Round-2 evidence after the LDS-DMA GEMM kernel and the two-workgroup persistent geometry, in one GPU call:
+# after the LDS-DMA GEMM kernel and the two-workgroup persistent geometry, in one GPU call:
 # kernel-trace statistics of the headline bench (alone, and with its variants), of the secondary
 # measurements, the HBM-side traffic passes and the SQ / GRBM counter passes of both fp64 kernels.
 # Results under gpurun_out/r02b_*; the summaries worth keeping are copied into profiles/ by hand.

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: every secondary measurement on the final build, unprofiled (event-timed lines) and under the kernel
+# every secondary measurement on the final build, unprofiled (event-timed lines) and under the kernel
 # trace (per-kernel durations), plus the fp32 extent sweep
 set -o pipefail
 R=$GRAFT_REPO_ROOT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3 evidence: HBM-side traffic of the headline kernel (two counter passes), kernel-trace statistics of
+# HBM-side traffic of the headline kernel (two counter passes), kernel-trace statistics of
 # bench.py (headline alone, then with its variants), instruction / busy counters of the headline kernel
 set -o pipefail
 R=$GRAFT_REPO_ROOT

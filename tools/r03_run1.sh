@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, first GPU pass: routing tests, slab rehearsal, routing sweep, bench line
+# routing tests, slab rehearsal, routing sweep, bench line
 set -o pipefail
 OUT=gpurun_out/r03a
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: what the config-4 slab gains when the A tile stops travelling L2 -> LDS per item (diagnostic build, wrong results)
+# what the config-4 slab gains when the A tile stops travelling L2 -> LDS per item (diagnostic build, wrong results)
 set -o pipefail
 OUT=gpurun_out/r03b
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: counters of the config-4 slab on the persistent kernel, regular build and the diagnostic build whose
+# counters of the config-4 slab on the persistent kernel, regular build and the diagnostic build whose
 # A tile is fetched once per workgroup (wrong results; two thirds of the L2 -> LDS bytes gone)
 set -o pipefail
 OUT=$PWD/gpurun_out/r03c

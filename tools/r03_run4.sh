@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: stream-K shares - parity first, then the extent sweep, the slab rehearsal and the bench line
+# stream-K shares - parity first, then the extent sweep, the slab rehearsal and the bench line
 set -o pipefail
 OUT=$PWD/gpurun_out/r03d
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: stream-K shares formed over groups of g tiles (g workgroups in K lock-step): parity, then g = 1, 8, 16, 64
+# stream-K shares formed over groups of g tiles (g workgroups in K lock-step): parity, then g = 1, 8, 16, 64
 set -o pipefail
 OUT=$PWD/gpurun_out/r03e
 mkdir -p $OUT

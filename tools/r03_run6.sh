@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: the whole GPU suite, then sweep / rehearsal / bench on the schedule chosen by cost
+# the whole GPU suite, then sweep / rehearsal / bench on the schedule chosen by cost
 set -o pipefail
 OUT=$PWD/gpurun_out/r03f
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: bench.py rehearsals on one GPU - two ranks over gloo sharing the card (strong-scaling path, variants),
+# bench.py rehearsals on one GPU - two ranks over gloo sharing the card (strong-scaling path, variants),
 # the watchdog (time-out on record, non-zero exit), and the kernel trace of the headline alone
 set -o pipefail
 R=$GRAFT_REPO_ROOT

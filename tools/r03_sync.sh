@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3 diagnostic: item-walking workgroups of an XCD meet after every round (bounded wait) - time and HBM-side traffic
+# item-walking workgroups of an XCD meet after every round (bounded wait) - time and HBM-side traffic
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/r03k
