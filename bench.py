@@ -57,6 +57,16 @@ def cpu_baseline(extent, threads):
     return 2.0 * n ** 6 / dt * 1e-12, dt, float(np.abs(C).max())
 
 
+def cpu_sample_extent(threads):
+    """The CPU sample is bounded: the largest extent whose 2 n^6 flops take at most about 30 s at 5 GFLOP/s
+    per thread (the oracle measures 7-12 per thread).  A launcher that sets OMP_NUM_THREADS=1 for its
+    workers must not turn the sample into minutes that the other ranks spend at a barrier."""
+    for n in (96, 80, 64):
+        if 2.0 * n ** 6 <= 30.0 * 5e9 * threads:
+            return n
+    return 48
+
+
 def cpu_threads():
     """Host threads the CPU baseline runs on: the process's CPU share (its affinity mask, capped by
     OMP_NUM_THREADS when the environment sets one: on a shared GPU host os.cpu_count() counts the whole
@@ -348,7 +358,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--extent", type=int, default=96, help="extent of every mode (64..96 in BASELINE)")
-    ap.add_argument("--cpu-extent", type=int, default=96, help="extent of the CPU-oracle sample")
+    ap.add_argument("--cpu-extent", type=int, default=0,
+                    help="extent of the CPU-oracle sample (0: the largest of 96 / 80 / 64 / 48 that the host threads finish in about 30 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary measurements (config.variants)")
     ap.add_argument("--no-verify", action="store_true", help="skip the check of the result against the CPU oracle")
@@ -495,13 +506,14 @@ def main():
         if not args.no_cpu:
             # the CPU column, at every N: rank 0's host cores, while the other ranks wait at the next barrier
             threads = cpu_threads()
-            tf, dt, _ = cpu_baseline(args.cpu_extent, threads)
+            cpu_n = args.cpu_extent or cpu_sample_extent(threads)
+            tf, dt, _ = cpu_baseline(cpu_n, threads)
             out["cpu_baseline"] = {
                 "value": round(tf, 5), "unit": "TFLOP/s", "cores": threads, "threads": threads,
                 "host_logical_cpus": os.cpu_count(), "kind": "port",
                 "sample": "same contraction at all extents %d (2*%d^6 flops, %.1f s) on the build's own CPU "
                           "oracle (OpenMP over the outermost free index, every CPU of this job's share); the "
-                          "reference has no CPU contraction path" % (args.cpu_extent, args.cpu_extent, dt),
+                          "reference has no CPU contraction path" % (cpu_n, cpu_n, dt),
             }
             offer(out)
 
