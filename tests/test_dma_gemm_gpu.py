@@ -222,9 +222,13 @@ def _random_share_cases(count, seed=20240917):
     return out
 
 
-@pytest.mark.parametrize("spec,ext,dtype,group", _random_share_cases(24),
+# CTC_SK_FUZZ_CASES / CTC_SK_FUZZ_SEED: more shapes, another sequence (one-off campaigns beside the fixed suite)
+_SHARE_CASES = _random_share_cases(int(os.environ.get("CTC_SK_FUZZ_CASES", "24")), int(os.environ.get("CTC_SK_FUZZ_SEED", "20240917"), 0))
+
+
+@pytest.mark.parametrize("spec,ext,dtype,group", _SHARE_CASES,
                          ids=["%s_%dx%dx%d_%s_g%d" % (c[0].replace(",", "_").replace("->", "_"), c[1]["a"], c[1]["b"], c[1]["k"], c[2], c[3])
-                              for c in _random_share_cases(24)])
+                              for c in _SHARE_CASES])
 def test_stream_k_shares_random_shapes(cuda, spec, ext, dtype, group):
     """Seeded random shapes (tile counts from below one round of workgroup slots to several, ragged edges, all
     four layout pairs, every group size) with stream-K shares forced, against the same plan with equal K chunks:
