@@ -365,7 +365,7 @@ def test_seeded_random_contractions_on_large_tiles(cuda, oracle):
     128 x 128 tile (the generic random test draws small ones): whichever kernel the launch takes must
     match the oracle, and the LDS-DMA kernel must take a fair share of them."""
     import random
-    rng = random.Random(0xD3A)
+    rng = random.Random(0xD3A ^ int(os.environ.get("CTC_SK_FUZZ_SEED", "0"), 0) if "CTC_SK_FUZZ_SEED" in os.environ else 0xD3A)
     took_dma = 0
     n_cases = int(os.environ.get("CTC_DMA_FUZZ_CASES", "30"))
     for n in range(n_cases):
