@@ -568,6 +568,7 @@ int ctc_tc_plan_create(const char *spec, int n_ext, const char *mode_names, cons
                        const int64_t *strides_a, const int64_t *strides_b, const int64_t *strides_c,
                        int dtype, ctc_tc_plan **plan)
 {
+    CTC_ABI_TRY
     if (!spec || !plan || n_ext < 0 || (n_ext > 0 && (!mode_names || !extents)))
         return fail(CTC_TC_EINVAL, "null argument");
     std::unique_ptr<ctc_tc_plan> pl(new ctc_tc_plan());
@@ -577,6 +578,7 @@ int ctc_tc_plan_create(const char *spec, int n_ext, const char *mode_names, cons
                                     ? CTC_TC_ESPEC : CTC_TC_EINVAL, e);
     *plan = pl.release();
     return CTC_TC_OK;
+    CTC_ABI_CATCH
 }
 
 int ctc_tc_plan_destroy(ctc_tc_plan *plan)
@@ -590,6 +592,7 @@ int ctc_tc_plan_destroy(ctc_tc_plan *plan)
 
 int ctc_tc_plan_describe(const ctc_tc_plan *plan, char *buf, size_t buflen)
 {
+    CTC_ABI_TRY
     if (!plan) return fail(CTC_TC_EINVAL, "null plan");
     std::string s = ctc::describe(plan->plan);
     if (buf && buflen) {
@@ -598,10 +601,12 @@ int ctc_tc_plan_describe(const ctc_tc_plan *plan, char *buf, size_t buflen)
         buf[n] = 0;
     }
     return (int)s.size();
+    CTC_ABI_CATCH
 }
 
 int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_t cap)
 {
+    CTC_ABI_TRY
     if (!plan) return fail(CTC_TC_EINVAL, "null plan");
     const ctc::Plan &p = plan->plan;
     std::vector<int64_t> v;
@@ -657,11 +662,13 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
     default: return fail(CTC_TC_EINVAL, "unknown query");
     }
     return copy_out(v, out, cap);
+    CTC_ABI_CATCH
 }
 
 int ctc_tc_plan_shard(const ctc_tc_plan *plan, char mode, int rank, int nranks, ctc_tc_plan **shard,
                       int64_t *off_a, int64_t *off_b, int64_t *off_c)
 {
+    CTC_ABI_TRY
     if (!plan || !shard) return fail(CTC_TC_EINVAL, "null argument");
     std::unique_ptr<ctc_tc_plan> pl(new ctc_tc_plan());
     int64_t oa = 0, ob = 0, oc = 0;
@@ -672,10 +679,12 @@ int ctc_tc_plan_shard(const ctc_tc_plan *plan, char mode, int rank, int nranks, 
     if (off_c) *off_c = oc;
     *shard = pl.release();
     return CTC_TC_OK;
+    CTC_ABI_CATCH
 }
 
 int ctc_tc_plan_prepare(ctc_tc_plan *plan)
 {
+    CTC_ABI_TRY
     if (!plan) return fail(CTC_TC_EINVAL, "null plan");
     int device = 0;
     int rc = current_device(device);
@@ -709,11 +718,13 @@ int ctc_tc_plan_prepare(ctc_tc_plan *plan)
         rc = grow_workspace(plan->tables[device], bytes);
     }
     return rc;
+    CTC_ABI_CATCH
 }
 
 int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta, void *C,
                    void *stream)
 {
+    CTC_ABI_TRY
     if (!plan || !A || !B || !C) return fail(CTC_TC_EINVAL, "null argument");
     static const bool no_auto = getenv("CTC_TC_NO_AUTO_TTGT") != nullptr;
     if (plan->plan.prefer_transposes && beta == 0.0 && !no_auto) {
@@ -751,6 +762,7 @@ int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B
         return CTC_TC_OK;
     }
     return launch_plan(plan, alpha, A, B, beta, C, static_cast<hipStream_t>(stream));
+    CTC_ABI_CATCH
 }
 
 int64_t ctc_tc_noalloc_scratch_bytes(void) { return (int64_t)kScratchBytes; }
@@ -758,6 +770,7 @@ int64_t ctc_tc_noalloc_scratch_bytes(void) { return (int64_t)kScratchBytes; }
 int ctc_tc_execute_noalloc(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta, void *C,
                            void *stream)
 {
+    CTC_ABI_TRY
     if (!plan || !A || !B || !C) return fail(CTC_TC_EINVAL, "null argument");
     int device = 0;
     int rc = current_device(device);
@@ -775,11 +788,13 @@ int ctc_tc_execute_noalloc(ctc_tc_plan *plan, double alpha, const void *A, const
     ws.fixed = scratch_dev;
     ws.fixed_bytes = kScratchBytes;
     return launch_plan(plan, alpha, A, B, beta, C, static_cast<hipStream_t>(stream), &ws, /*no_alloc=*/true);
+    CTC_ABI_CATCH
 }
 
 int ctc_tc_permute(const void *in, void *out, int rank, const int64_t *extents_in, const int *perm,
                    int elem_size, void *stream)
 {
+    CTC_ABI_TRY
     if (!in || !out || !extents_in || !perm) return fail(CTC_TC_EINVAL, "null argument");
     if (in == out) return fail(CTC_TC_EINVAL, "in-place permutation is not supported");
     int device = 0;
@@ -795,6 +810,7 @@ int ctc_tc_permute(const void *in, void *out, int rank, const int64_t *extents_i
     hipError_t e = ctc::launch_permute(elem_size, p, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "permute kernel launch");
     return CTC_TC_OK;
+    CTC_ABI_CATCH
 }
 
 int64_t ctc_tc_ttgt_workspace_bytes(const ctc_tc_plan *plan)
@@ -809,6 +825,7 @@ int64_t ctc_tc_ttgt_workspace_bytes(const ctc_tc_plan *plan)
 int ctc_tc_execute_ttgt(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta,
                         void *C, void *workspace, int64_t workspace_bytes, void *stream)
 {
+    CTC_ABI_TRY
     if (!plan || !A || !B || !C || !workspace) return fail(CTC_TC_EINVAL, "null argument");
     if (beta != 0.0) return fail(CTC_TC_EUNSUPPORTED, "the explicit-transpose path supports beta == 0 only");
     const ctc::Plan &p = plan->plan;
@@ -846,6 +863,7 @@ int ctc_tc_execute_ttgt(ctc_tc_plan *plan, double alpha, const void *A, const vo
     if (rc) return rc;
     // [batch,M,N] -> C
     return ctc_tc_permute(wc, C, (int)ts.eg.size(), ts.eg.data(), p.perm_c.data(), es, stream);
+    CTC_ABI_CATCH
 }
 
 int ctc_tc_grouped_contract(const ctc_tc_small_gemm *problems, int count, int dtype, double alpha, const void *A,
@@ -871,6 +889,7 @@ int ctc_tc_fill(void *dev, int64_t n, uint64_t seed, int64_t first, int dtype, v
 int ctc_tc_time_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta,
                         void *C, void *stream, int warmup, int iters, double *avg_ms)
 {
+    CTC_ABI_TRY
     if (!plan || !avg_ms || iters <= 0 || warmup < 0) return fail(CTC_TC_EINVAL, "bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int i = 0; i < warmup; ++i) {
@@ -895,11 +914,13 @@ int ctc_tc_time_execute(ctc_tc_plan *plan, double alpha, const void *A, const vo
     if (e != hipSuccess) return fail_hip(e, "event timing");
     *avg_ms = (double)ms / iters;
     return CTC_TC_OK;
+    CTC_ABI_CATCH
 }
 
 int ctc_tc_time_execute_each(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta,
                              void *C, void *stream, int iters, double *ms_each)
 {
+    CTC_ABI_TRY
     if (!plan || !ms_each || iters <= 0 || iters > 4096) return fail(CTC_TC_EINVAL, "bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     std::vector<hipEvent_t> ev((size_t)iters + 1, nullptr);
@@ -925,6 +946,7 @@ int ctc_tc_time_execute_each(ctc_tc_plan *plan, double alpha, const void *A, con
     if (rc) return rc;
     if (e != hipSuccess) return fail_hip(e, "event timing");
     return CTC_TC_OK;
+    CTC_ABI_CATCH
 }
 
 }  // extern "C"

@@ -7,6 +7,8 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -37,6 +39,17 @@ struct DeviceTables {
 
 int set_last_error(int code, const std::string &msg);
 int set_last_hip_error(hipError_t e, const char *what);
+
+// No C++ exception leaves the C ABI: the body of an entry point that allocates host memory (plans, offset
+// tables, strings) stands between these two.
+#define CTC_ABI_TRY try {
+#define CTC_ABI_CATCH                                                                                           \
+    }                                                                                                           \
+    catch (const std::bad_alloc &) { return ctc_internal::set_last_error(CTC_TC_ENOMEM, "out of host memory"); } \
+    catch (const std::exception &e)                                                                             \
+    {                                                                                                           \
+        return ctc_internal::set_last_error(CTC_TC_EINVAL, std::string("internal error: ") + e.what());         \
+    }
 
 }  // namespace ctc_internal
 

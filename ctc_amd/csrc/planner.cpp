@@ -230,6 +230,35 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
         if (m.extent < 0) return std::string("missing extent for mode '") + m.name + "'";
         if (m.extent == 0) return std::string("zero extent for mode '") + m.name + "'";
     }
+    // Sizes stay far inside int64: an operand has at most 2^46 elements (packed count, and the span its strides
+    // address), a GEMM dimension at most 2^31 - 1 entries (one int64 table entry per row / column / k / batch).
+    constexpr int64_t kMaxElems = int64_t(1) << 46, kMaxDim = 0x7FFFFFFF;
+    auto product_within = [&](const std::vector<int> &modes, int64_t limit) {
+        int64_t n = 1;
+        for (int id : modes) {
+            if (p.modes[id].extent > limit / n) return false;
+            n *= p.modes[id].extent;
+        }
+        return true;
+    };
+    if (!product_within(p.a_modes, kMaxElems) || !product_within(p.b_modes, kMaxElems) || !product_within(p.c_modes, kMaxElems))
+        return "operand too large (more than 2^46 elements)";
+    if (!product_within(p.canon_batch, kMaxDim) || !product_within(p.canon_m, kMaxDim) || !product_within(p.canon_n, kMaxDim) ||
+        !product_within(p.canon_k, kMaxDim))
+        return "contraction too large (a GEMM dimension of 2^31 or more)";
+    auto span_within = [&](const std::vector<int> &modes, const int64_t *given) {
+        if (!given) return true;
+        int64_t span = 1;
+        for (size_t i = 0; i < modes.size(); ++i) {
+            const int64_t e1 = p.modes[modes[i]].extent - 1, s = given[i];
+            if (s < 0) return true;  // reported below
+            if (e1 > 0 && s > (kMaxElems - span) / e1) return false;
+            span += e1 * s;
+        }
+        return true;
+    };
+    if (!span_within(p.a_modes, strides_a) || !span_within(p.b_modes, strides_b) || !span_within(p.c_modes, strides_c))
+        return "operand too large (its strides address more than 2^46 elements)";
     std::vector<int64_t> st;
     auto assign = [&](const std::vector<int> &modes, const int64_t *given, int which) {
         if (given) st.assign(given, given + modes.size()); else packed_strides(p, modes, st);

@@ -136,6 +136,7 @@ int ctc_tc_comm_abort(void *comm)
 int ctc_tc_sharded_create(const char *spec, int n_ext, const char *mode_names, const int64_t *extents, int dtype,
                           char mode, int rank, int nranks, int nchunks, int reduce, ctc_tc_sharded **out)
 {
+    CTC_ABI_TRY
     if (!spec || !mode_names || !extents || !out || n_ext <= 0) return set_last_error(CTC_TC_EINVAL, "null argument");
     if (nranks < 1 || rank < 0 || rank >= nranks) return set_last_error(CTC_TC_EINVAL, "bad rank/nranks");
     if (reduce != CTC_TC_REDUCE_SCATTER && reduce != CTC_TC_ALL_REDUCE) return set_last_error(CTC_TC_EINVAL, "bad reduce kind");
@@ -250,6 +251,7 @@ int ctc_tc_sharded_create(const char *spec, int n_ext, const char *mode_names, c
     }
     *out = s.release();
     return CTC_TC_OK;
+    CTC_ABI_CATCH
 }
 
 int ctc_tc_sharded_destroy(ctc_tc_sharded *s)
@@ -297,15 +299,18 @@ ctc_tc_plan *ctc_tc_sharded_chunk_plan(const ctc_tc_sharded *s, int chunk)
 
 int ctc_tc_sharded_prepare(ctc_tc_sharded *s)
 {
+    CTC_ABI_TRY
     if (!s) return set_last_error(CTC_TC_EINVAL, "null argument");
     int rc = ensure_streams(s);
     for (size_t c = 0; c < s->chunks.size() && rc == CTC_TC_OK; ++c) rc = ctc_tc_plan_prepare(s->chunks[c].plan.get());
     return rc;
+    CTC_ABI_CATCH
 }
 
 int ctc_tc_sharded_execute(ctc_tc_sharded *s, void *nccl_comm, double alpha, const void *A, const void *B, void *C,
                            void *workspace, int64_t workspace_bytes, void *stream)
 {
+    CTC_ABI_TRY
     if (!s || !A || !B || !C) return set_last_error(CTC_TC_EINVAL, "null argument");
     if (!nccl_comm && s->nranks > 1 && s->reduce == CTC_TC_REDUCE_SCATTER)
         return set_last_error(CTC_TC_EINVAL, "null communicator (without one only the all-reduce form runs: it then leaves "
@@ -350,6 +355,7 @@ int ctc_tc_sharded_execute(ctc_tc_sharded *s, void *nccl_comm, double alpha, con
     if (e == hipSuccess) e = hipStreamWaitEvent(compute, s->all_done, 0);
     if (e != hipSuccess) return set_last_hip_error(e, "joining the communication stream");
     return CTC_TC_OK;
+    CTC_ABI_CATCH
 }
 
 }  // extern "C"
