@@ -28,6 +28,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -76,7 +78,8 @@ void write_file(const std::string &path, const void *data, size_t bytes)
 
 }  // namespace
 
-int main(int argc, char **argv)
+namespace {
+int run(int argc, char **argv)
 {
     std::map<std::string, std::string> opt;
     bool describe = false;
@@ -135,6 +138,7 @@ int main(int argc, char **argv)
             size_t at = names.find(ch);
             if (at == std::string::npos) die(std::string("no extent for mode ") + ch);
             if (in_modes.find(ch) != in_modes.rfind(ch)) die(std::string("mode repeated in --permute: ") + ch);
+            if (extents[at] < 1 || (size_t)extents[at] > (size_t(1) << 46) / n) die("--permute: bad extent or tensor too large");
             ext_in.push_back(extents[at]);
             n *= (size_t)extents[at];
         }
@@ -479,4 +483,17 @@ int main(int argc, char **argv)
     (void)hipFree(dB);
     (void)hipFree(dC);
     return 0;
+}
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    // a size the host cannot hold (extents that do not describe the files) ends as a message, not as an abort
+    try {
+        return run(argc, argv);
+    } catch (const std::bad_alloc &) {
+        die("out of host memory (do the extents describe the tensors?)");
+    } catch (const std::exception &e) {
+        die(std::string("internal error: ") + e.what());
+    }
 }

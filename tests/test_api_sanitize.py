@@ -36,3 +36,14 @@ def test_sizes_that_would_overflow_are_refused():
     # a stride that reaches past 2^46 elements
     with pytest.raises(ctc_amd.CtcError, match="too large"):
         ctc_amd.Plan("ab,bc->ac", dict(a=1024, b=4, c=4), "f64", strides_a=[1 << 40, 1])
+
+
+def test_tool_refuses_sizes_it_cannot_hold(tmp_path):
+    """ctc_contract with extents no tensor file can have: a message and exit status 2, no abort."""
+    tool = os.path.join(ROOT, "ctc_amd", "bin", "ctc_contract")
+    big = "a=1099511627776,b=1099511627776"
+    r = subprocess.run([tool, "--permute", "ab=ba", "--extents", big, "--a", os.devnull, "--out", str(tmp_path / "x")],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "too large" in r.stderr, (r.returncode, r.stderr)
+    r = subprocess.run([tool, "--spec", "ab,bc=ac", "--extents", big + ",c=4", "--describe"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "too large" in r.stderr, (r.returncode, r.stderr)
