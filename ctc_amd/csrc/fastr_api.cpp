@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,7 @@ extern "C" int ctc_fastr_best_offsets(const uint8_t *d_ref, const uint8_t *d_rea
                                       void *stream)
 {
     using ctc_internal::set_last_error;
+    try {  // the work table is host memory: no exception leaves the C ABI
     if (n_regions < 0 || read_stride <= 0) return set_last_error(CTC_TC_EINVAL, "bad n_regions or read_stride");
     if (n_regions == 0) return CTC_TC_OK;
     if (!d_ref || !d_read_seq || !d_quals || !d_read_len || !d_original_alignment || !h_n_consensus || !h_alt_reads ||
@@ -127,6 +129,9 @@ extern "C" int ctc_fastr_best_offsets(const uint8_t *d_ref, const uint8_t *d_rea
     (void)hipEventRecord(st.done, s);  // also after a failed launch: the upload still reads st.host
     if (e != hipSuccess) return set_last_error(CTC_TC_EDEVICE, std::string("scoring kernel launch: ") + hipGetErrorString(e));
     return CTC_TC_OK;
+    } catch (const std::bad_alloc &) {
+        return set_last_error(CTC_TC_ENOMEM, "out of host memory for the work table");
+    }
 }
 
 extern "C" size_t ctc_fastr_sw_workspace_bytes(int n_pairs, int max_ref_len, int max_read_len)

@@ -2,6 +2,7 @@
 // UndefinedBehaviorSanitizer, on a machine WITHOUT a GPU: every entry point that needs no device is driven with
 // seeded random specs, short and exact output buffers, invalid arguments; entry points that need a device must
 // come back with an error code.  Built and run by tools/api_sanitize.sh.
+#include "ctc_fastr.h"
 #include "ctc_tc.h"
 
 #include <algorithm>
@@ -249,6 +250,30 @@ static void bad_arguments()
     EXPECT(ctc_tc_grouped_contract(nullptr, 3, 0, 1.0, d, d, 0.0, d, nullptr) != CTC_TC_OK, "grouped without descriptors");
     EXPECT(ctc_tc_device_count() == 0, "device count");
     EXPECT(ctc_tc_version() > 0 && ctc_tc_noalloc_scratch_bytes() > 0, "version / scratch size");
+    // the scoring / alignment entry points: argument checks come before anything touches a device
+    {
+        const uint8_t *u8 = reinterpret_cast<const uint8_t *>(d);
+        const int32_t *i32 = reinterpret_cast<const int32_t *>(d);
+        int32_t *o32 = reinterpret_cast<int32_t *>(d);
+        const int32_t ncons[2] = {2, 1}, reads[2] = {3, 4}, lens[3] = {200, 300, 250}, neg[2] = {2, -1}, neg_len[3] = {200, -5, 250};
+        EXPECT(ctc_fastr_best_offsets(u8, u8, u8, 100, i32, i32, 0, ncons, reads, lens, o32, o32, nullptr) == CTC_TC_OK, "no regions");
+        EXPECT(ctc_fastr_best_offsets(u8, u8, u8, 100, i32, i32, -1, ncons, reads, lens, o32, o32, nullptr) == CTC_TC_EINVAL, "negative regions");
+        EXPECT(ctc_fastr_best_offsets(u8, u8, u8, 0, i32, i32, 2, ncons, reads, lens, o32, o32, nullptr) == CTC_TC_EINVAL, "zero stride");
+        EXPECT(ctc_fastr_best_offsets(nullptr, u8, u8, 100, i32, i32, 2, ncons, reads, lens, o32, o32, nullptr) == CTC_TC_EINVAL, "null ref");
+        EXPECT(ctc_fastr_best_offsets(u8, u8, u8, 100, i32, i32, 2, neg, reads, lens, o32, o32, nullptr) == CTC_TC_EINVAL, "negative count");
+        EXPECT(ctc_fastr_best_offsets(u8, u8, u8, 100, i32, i32, 2, ncons, neg, lens, o32, o32, nullptr) == CTC_TC_EINVAL, "negative reads");
+        EXPECT(ctc_fastr_best_offsets(u8, u8, u8, 100, i32, i32, 2, ncons, reads, neg_len, o32, o32, nullptr) == CTC_TC_EINVAL, "negative length");
+        EXPECT(ctc_fastr_best_offsets(u8, u8, u8, 100, i32, i32, 2, ncons, reads, lens, o32, o32, nullptr) == CTC_TC_EDEVICE, "scoring without a device");
+        EXPECT(ctc_fastr_sw_workspace_bytes(0, 100, 100) == 0 && ctc_fastr_sw_workspace_bytes(10, 100, 100) > 0, "alignment workspace size");
+        uint8_t *o8 = reinterpret_cast<uint8_t *>(d);
+        const int64_t *i64 = reinterpret_cast<const int64_t *>(d);
+        EXPECT(ctc_fastr_sw_align(u8, i64, i32, u8, 100, i32, 0, 1, -1, -2, -1, 100, 100, o32, o32, o8, o32, 8, d, 1 << 20, nullptr) == CTC_TC_OK, "no pairs");
+        EXPECT(ctc_fastr_sw_align(u8, i64, i32, u8, 100, i32, 4, 1, -1, -2, -1, 40000, 100, o32, o32, o8, o32, 8, d, 1 << 20, nullptr) == CTC_TC_EUNSUPPORTED, "window too long");
+        EXPECT(ctc_fastr_sw_align(u8, i64, i32, u8, 100, i32, 4, 1, -1, -2, -1, 100, 200, o32, o32, o8, o32, 8, d, 1 << 20, nullptr) == CTC_TC_EINVAL, "read longer than its slot");
+        EXPECT(ctc_fastr_sw_align(u8, i64, i32, u8, 100, i32, 4, 1, -1, -2, -1, 100, 100, o32, o32, o8, o32, 8, d, 16, nullptr) == CTC_TC_EINVAL, "workspace too small");
+        EXPECT(ctc_fastr_sw_align(u8, i64, i32, u8, 100, i32, 4, 1, -1, -2, -1, 100, 100, o32, o32, o8, o32, 0, d, 1 << 20, nullptr) == CTC_TC_EINVAL, "no room for operations");
+        EXPECT(ctc_fastr_sw_align(u8, i64, i32, u8, 100, i32, 4, 1, -1, -2, -1, 100, 100, o32, o32, o8, o32, 8, nullptr, 1 << 20, nullptr) == CTC_TC_EINVAL, "null workspace");
+    }
     unsigned char id[CTC_TC_UNIQUE_ID_BYTES];
     (void)ctc_tc_comm_unique_id(id);
     (void)ctc_tc_comm_destroy(nullptr);
