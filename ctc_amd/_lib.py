@@ -42,6 +42,7 @@ Q_GEMM_DIMS, Q_TILE = 15, 16
 Q_ROW_A, Q_K_A, Q_K_B, Q_COL_B, Q_ROW_C, Q_COL_C, Q_BAT_A, Q_BAT_B, Q_BAT_C = range(17, 26)
 Q_FLOPS = 26
 Q_SCHEDULE = 27
+Q_SPANS = 28
 
 
 class CtcError(RuntimeError):

@@ -659,6 +659,16 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
              (int64_t)worst_splitk_bytes(p), sch.sk_units};
         break;
     }
+    case CTC_TC_Q_SPANS: {
+        int64_t a = 1, b = 1, c = 1;  // a mode an operand lacks has stride 0 there
+        for (auto &m : p.modes) {
+            a += (m.extent - 1) * m.sa;
+            b += (m.extent - 1) * m.sb;
+            c += (m.extent - 1) * m.sc;
+        }
+        v = {a, b, c};
+        break;
+    }
     default: return fail(CTC_TC_EINVAL, "unknown query");
     }
     return copy_out(v, out, cap);

@@ -44,6 +44,13 @@ def _ptr(x):
     return ctypes.c_void_p(x.data_ptr())
 
 
+def _room(x):
+    """Elements from x's first element to the end of the storage behind it (None for a raw address)."""
+    if x is None or isinstance(x, int):
+        return None
+    return x.untyped_storage().nbytes() // x.element_size() - x.storage_offset()
+
+
 def _stream(stream):
     if stream is None:
         try:
@@ -184,7 +191,30 @@ class Plan:
     def prepare(self):
         check(self._lib.ctc_tc_plan_prepare(self._h))
 
+    def spans(self):
+        """Elements of A, B and C an execution addresses, counted from the pointers it is given."""
+        if getattr(self, "_spans", None) is None:
+            self._spans = tuple(self.get(_lib.Q_SPANS))
+        return self._spans
+
+    def _check_operands(self, A, B, C):
+        """The kernels trust their offset tables: a buffer shorter than the plan addresses, or of another
+        element size, would be read or written past its end on the device.  Tensors are checked here, before
+        anything is launched; raw addresses (ints) cannot be."""
+        for name, x, need in zip("ABC", (A, B, C), self.spans()):
+            if x is None:
+                raise ValueError("operand %s is None" % name)
+            if isinstance(x, int):
+                continue
+            if x.element_size() != DTYPE_SIZE[self.dtype]:
+                raise ValueError("operand %s has %d-byte elements, the plan was made for %d-byte ones"
+                                 % (name, x.element_size(), DTYPE_SIZE[self.dtype]))
+            if _room(x) < need:
+                raise ValueError("operand %s holds %d elements from its first one on, the plan addresses %d"
+                                 % (name, _room(x), need))
+
     def execute(self, A, B, C, alpha=1.0, beta=0.0, stream=None):
+        self._check_operands(A, B, C)
         check(self._lib.ctc_tc_execute(self._h, float(alpha), _ptr(A), _ptr(B), float(beta), _ptr(C),
                                        _stream(stream)))
         return C
@@ -192,6 +222,7 @@ class Plan:
     def execute_noalloc(self, A, B, C, alpha=1.0, beta=0.0, stream=None):
         """execute() through the library's fixed per-GPU scratch buffer: no device allocation.  Needs
         prepare() first; calls that overlap on one GPU race (they share the buffer)."""
+        self._check_operands(A, B, C)
         check(self._lib.ctc_tc_execute_noalloc(self._h, float(alpha), _ptr(A), _ptr(B), float(beta), _ptr(C),
                                                _stream(stream)))
         return C
@@ -200,13 +231,15 @@ class Plan:
         return int(check(self._lib.ctc_tc_ttgt_workspace_bytes(self._h)))
 
     def execute_ttgt(self, A, B, C, workspace, alpha=1.0, beta=0.0, stream=None):
-        nbytes = workspace.numel() * workspace.element_size()
+        self._check_operands(A, B, C)
+        nbytes = min(workspace.numel(), _room(workspace)) * workspace.element_size()
         check(self._lib.ctc_tc_execute_ttgt(self._h, float(alpha), _ptr(A), _ptr(B), float(beta), _ptr(C),
                                             _ptr(workspace), nbytes, _stream(stream)))
         return C
 
     def time(self, A, B, C, warmup=2, iters=10, alpha=1.0, beta=0.0, stream=None):
         """Average device milliseconds per execution, from HIP events on the launch stream."""
+        self._check_operands(A, B, C)
         ms = ctypes.c_double()
         check(self._lib.ctc_tc_time_execute(self._h, float(alpha), _ptr(A), _ptr(B), float(beta), _ptr(C),
                                             _stream(stream), warmup, iters, ctypes.byref(ms)))
@@ -214,6 +247,7 @@ class Plan:
 
     def time_each(self, A, B, C, iters=10, alpha=1.0, beta=0.0, stream=None):
         """Device milliseconds of each of `iters` back-to-back executions (an event between every two)."""
+        self._check_operands(A, B, C)
         ms = (ctypes.c_double * iters)()
         check(self._lib.ctc_tc_time_execute_each(self._h, float(alpha), _ptr(A), _ptr(B), float(beta), _ptr(C),
                                                  _stream(stream), iters, ms))
@@ -248,6 +282,8 @@ def permute(x, perm, out=None, stream=None):
     perm = [int(p) for p in perm]
     if out is None:
         out = torch.empty([x.shape[p] for p in perm], dtype=x.dtype, device=x.device)
+    elif out.element_size() != x.element_size() or _room(out) < x.numel() or not out.is_contiguous():
+        raise ValueError("permute: the result must be packed, of the input's element size and hold %d elements" % x.numel())
     ext = _i64_array(x.shape)
     pm = (ctypes.c_int * len(perm))(*perm)
     check(L.ctc_tc_permute(_ptr(x), _ptr(out), x.dim(), ext, pm, x.element_size(), _stream(stream)))
@@ -257,6 +293,8 @@ def permute(x, perm, out=None, stream=None):
 def fill(x, seed, first=0, stream=None):
     """Fill a packed device tensor with the synthetic stream uniform[-1,1) of splitmix64(seed + first + k)."""
     L = _lib.load()
+    if not x.is_contiguous():
+        raise ValueError("fill expects a packed tensor")
     check(L.ctc_tc_fill(_ptr(x), x.numel(), ctypes.c_uint64(seed), int(first), _dtype_code(x.dtype),
                         _stream(stream)))
     return x

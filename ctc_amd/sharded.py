@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .host import CLASS_NAMES, Plan, _dtype_code, _i64_array, _ptr, _stream, check  # noqa: F401
+from .host import CLASS_NAMES, Plan, _dtype_code, _i64_array, _ptr, _room, _stream, check  # noqa: F401
 
 
 def _numel(letters, extents):
@@ -165,6 +165,11 @@ class ShardedContraction:
             if partial.numel() < n_ws:
                 raise ValueError("scratch holds %d elements, %d needed" % (partial.numel(), n_ws))
         if compute is None:
+            # the C layer takes raw pointers: sizes are checked here, before anything is launched
+            for name, x, need in (("A", A, self.local_numel("a")), ("B", B, self.local_numel("b")), ("C", C, self.out_numel())):
+                if x.element_size() != C.element_size() or _room(x) < need:
+                    raise ValueError("operand %s holds %d elements of %d bytes, this rank's part needs %d elements of the "
+                                     "result's element size" % (name, _room(x), x.element_size(), need))
             ws_bytes = n_ws * C.element_size() if scatter else 0
             check(self._lib.ctc_tc_sharded_execute(
                 self._h, comm._h if comm is not None else None, float(alpha), _ptr(A), _ptr(B), _ptr(C),

@@ -103,6 +103,11 @@ enum ctc_tc_query {
                                   fall-backs to element loads for unaligned bases, stream-K shares (0: the cut tiles
                                   are cut into `chunks per such tile` equal chunks; > 0: the K-tile iterations of the
                                   cut tiles, taken as one sequence, are dealt out in that many equal shares)} */
+    ,
+    CTC_TC_Q_SPANS = 28        /* {elements of A, of B, of C the plan addresses, counted from the pointer an execution
+                                  is given: 1 + the largest element offset (the packed element count for packed
+                                  operands; for a slab plan of ctc_tc_plan_shard, from the slab's first element)}.
+                                  What a host that knows its buffers' sizes checks before it launches. */
 };
 
 /* operand layouts reported in CTC_TC_Q_TILE */

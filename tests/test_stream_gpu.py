@@ -122,7 +122,10 @@ def test_automatic_routing_of_short_k(cuda):
         return (d[0] + d[1], d[2], d[3])
     x = torch.zeros(8192 * 256, dtype=torch.float64, device=cuda)  # the largest operand below: 8192 x 256
     c = torch.zeros(8192 * 8192, dtype=torch.float64, device=cuda)
-    run = lambda spec, ext, dt="f64", **kw: lambda: ctc_amd.Plan(spec, ext, dt).execute(x, x, c, **kw)  # noqa: E731
+    views = {"f64": (x, c), "f32": (x.view(torch.float32), c.view(torch.float32))}  # zeros in either element type
+
+    def run(spec, ext, dt="f64", **kw):
+        return lambda: ctc_amd.Plan(spec, ext, dt).execute(views[dt][0], views[dt][0], views[dt][1], **kw)
     assert ctc_amd.get_option("stream_mode") == 0
     assert delta(run("ak,kb->ab", dict(a=8192, b=8192, k=64))) == (0, 0, 1)
     assert delta(run("ak,kb->ab", dict(a=8192, b=8192, k=64), alpha=1.25)) == (0, 0, 1)

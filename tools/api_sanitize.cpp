@@ -31,7 +31,7 @@ static void queries(const ctc_tc_plan *p, const std::string &what)
 {
     for (int q = -1; q <= 30; ++q) {
         const int64_t n = ctc_tc_plan_get(p, q, nullptr, 0);
-        if (q < 0 || q > 27) {
+        if (q < 0 || q > CTC_TC_Q_SPANS) {
             EXPECT(n < 0, "%s: query %d must fail", what.c_str(), q);
             continue;
         }
