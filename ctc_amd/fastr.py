@@ -28,8 +28,35 @@ class DeviceBatch:
     ref, read_seq, quals (uint8), read_len, original_alignment (int32, one per read),
     n_consensus, alt_reads (int32, one per region), ref_lens (int32, one per consensus), read_stride."""
 
+    @staticmethod
+    def validate(batch):
+        """The kernel follows the counts and lengths of the batch without bounds checks (it only clamps read
+        lengths and original alignments): a batch whose arrays do not hold what its counts promise is
+        refused here, before anything is uploaded."""
+        n_cons = np.asarray(batch["n_consensus"], dtype=np.int64)
+        alt = np.asarray(batch["alt_reads"], dtype=np.int64)
+        ref_lens = np.asarray(batch["ref_lens"], dtype=np.int64)
+        read_len = np.asarray(batch["read_len"], dtype=np.int64)
+        stride = int(batch["read_stride"])
+        if stride <= 0:
+            raise ValueError("read_stride must be positive")
+        if n_cons.shape != alt.shape or (n_cons < 0).any() or (alt < 0).any():
+            raise ValueError("n_consensus and alt_reads: one non-negative count per region each")
+        n_reads = int(alt.sum())
+        if ref_lens.size != int(n_cons.sum()) or (ref_lens < 0).any():
+            raise ValueError("ref_lens: one non-negative length per consensus (%d expected, %d given)" % (int(n_cons.sum()), ref_lens.size))
+        if read_len.size != n_reads or np.asarray(batch["original_alignment"]).size != n_reads:
+            raise ValueError("read_len and original_alignment: one entry per read (%d reads)" % n_reads)
+        if ((read_len < 0) | (read_len > stride)).any():
+            raise ValueError("a read length lies outside 0..read_stride")
+        for name, need in (("ref", int(ref_lens.sum())), ("read_seq", n_reads * stride), ("quals", n_reads * stride)):
+            a = np.asarray(batch[name])
+            if a.dtype != np.uint8 or a.size < need:
+                raise ValueError("%s: %d bytes (uint8) needed, %d %s given" % (name, need, a.size, a.dtype))
+
     def __init__(self, batch, device):
         import torch
+        self.validate(batch)
         self.device = device
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
         self.ref = up(batch["ref"])
@@ -149,8 +176,30 @@ class DeviceAlignmentBatch:
     back), ref_off (int64) and ref_len (int32) per pair, reads (uint8 [pairs][read_stride]),
     read_len (int32), read_stride."""
 
+    @staticmethod
+    def validate(batch):
+        """Every window must lie inside `ref` and every read inside its slot: the kernel checks lengths against
+        the batch maxima only."""
+        ref_off = np.asarray(batch["ref_off"], dtype=np.int64)
+        ref_len = np.asarray(batch["ref_len"], dtype=np.int64)
+        read_len = np.asarray(batch["read_len"], dtype=np.int64)
+        stride = int(batch["read_stride"])
+        n = read_len.size
+        if stride <= 0 or ref_off.size != n or ref_len.size != n:
+            raise ValueError("ref_off, ref_len and read_len: one entry per pair; read_stride positive")
+        ref, reads = np.asarray(batch["ref"]), np.asarray(batch["reads"])
+        if ref.dtype != np.uint8 or reads.dtype != np.uint8 or reads.size < n * stride:
+            raise ValueError("ref and reads must be uint8, reads holding read_stride bytes per pair")
+        if n and ((ref_off < 0) | (ref_len < 0) | (ref_off + ref_len > ref.size)).any():
+            raise ValueError("a reference window lies outside ref")
+        if n and ((read_len < 0) | (read_len > stride)).any():
+            raise ValueError("a read length lies outside 0..read_stride")
+        if n and ref_len.max() > 32767:
+            raise ValueError("reference windows are limited to 32767 bases")
+
     def __init__(self, batch, device, max_ops=64, workspace_pairs=None):
         import torch
+        self.validate(batch)
         self.device = device
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
         self.ref = up(batch["ref"])

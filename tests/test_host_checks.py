@@ -78,3 +78,49 @@ def test_sharded_execute_checks_sizes():
         sc.execute(z(sc.local_numel("a")), z(sc.local_numel("b")), z(sc.out_numel() - 1), scratch=z(sc.workspace_numel()))
     with pytest.raises(ValueError, match="scratch holds"):
         sc.execute(z(sc.local_numel("a")), z(sc.local_numel("b")), z(sc.out_numel()), scratch=z(sc.workspace_numel() - 1))
+
+
+def _scoring_batch():
+    import numpy as np
+    stride = 8
+    return {"ref": np.zeros(30, np.uint8), "ref_lens": np.array([10, 12, 8], np.int32), "n_consensus": np.array([2, 1], np.int32),
+            "alt_reads": np.array([2, 3], np.int32), "read_seq": np.zeros(5 * stride, np.uint8), "quals": np.zeros(5 * stride, np.uint8),
+            "read_len": np.array([8, 7, 8, 3, 0], np.int32), "original_alignment": np.zeros(5, np.int32), "read_stride": stride}
+
+
+def test_scoring_batches_are_validated_before_upload():
+    import numpy as np
+    from ctc_amd.fastr import DeviceBatch
+    DeviceBatch.validate(_scoring_batch())
+    for key, value, msg in (("ref", np.zeros(29, np.uint8), "ref: 30 bytes"),
+                            ("ref_lens", np.array([10, 12], np.int32), "one non-negative length per consensus"),
+                            ("ref_lens", np.array([10, -1, 8], np.int32), "one non-negative length per consensus"),
+                            ("alt_reads", np.array([2, -3], np.int32), "non-negative count"),
+                            ("read_len", np.array([8, 7, 8, 3], np.int32), "one entry per read"),
+                            ("read_len", np.array([8, 7, 9, 3, 0], np.int32), "outside 0..read_stride"),
+                            ("quals", np.zeros(39, np.uint8), "quals: 40 bytes"),
+                            ("read_seq", np.zeros(40, np.int8), "read_seq: 40 bytes"),
+                            ("read_stride", 0, "read_stride must be positive")):
+        b = _scoring_batch()
+        b[key] = value
+        with pytest.raises(ValueError, match=msg):
+            DeviceBatch(b, "cpu")
+
+
+def test_alignment_batches_are_validated_before_upload():
+    import numpy as np
+    from ctc_amd.fastr import DeviceAlignmentBatch
+
+    def batch():
+        return {"ref": np.zeros(100, np.uint8), "ref_off": np.array([0, 40, 60], np.int64), "ref_len": np.array([40, 20, 40], np.int32),
+                "reads": np.zeros(3 * 16, np.uint8), "read_len": np.array([16, 10, 0], np.int32), "read_stride": 16}
+    DeviceAlignmentBatch.validate(batch())
+    for key, value, msg in (("ref_off", np.array([0, 40, 61], np.int64), "window lies outside ref"),
+                            ("ref_off", np.array([0, -1, 60], np.int64), "window lies outside ref"),
+                            ("ref_len", np.array([40, 20], np.int32), "one entry per pair"),
+                            ("read_len", np.array([17, 10, 0], np.int32), "outside 0..read_stride"),
+                            ("reads", np.zeros(47, np.uint8), "read_stride bytes per pair")):
+        b = batch()
+        b[key] = value
+        with pytest.raises(ValueError, match=msg):
+            DeviceAlignmentBatch(b, "cpu")
