@@ -117,3 +117,47 @@ def test_different_plans_from_different_threads(cuda, oracle):
         want = oracle.contract(spec, ext, hA, hB, dtype=code[dt]).astype(np.float64)
         got = results[i].astype(np.float64)
         assert np.abs(got - want).max() <= tol[dt] * np.abs(want).max(), (spec, dt)
+
+
+def test_scoring_from_several_threads(cuda):
+    """ctc_fastr_best_offsets stages its work table through a ring of four (pinned, device) buffer pairs per GPU:
+    six threads on six streams, different batches, more calls in flight than slots.  Every call's result must
+    equal the oracle's."""
+    import numpy as np
+    from oracle import fastr as ofastr
+    from ctc_amd import fastr
+    threads, reps = 6, 12
+    batches = [ofastr.make_batch(seed=500 + i, n_regions=3 + i, max_consensus=4, reads=(4, 14), read_len=48, ref_len=(100, 400))
+               for i in range(threads)]
+    wants = [ofastr.best_offsets(b) for b in batches]
+    errors, bad = [], []
+    gate = threading.Barrier(threads)
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(cuda)
+            s = torch.cuda.Stream(device=cuda)
+            with torch.cuda.stream(s):
+                d = fastr.DeviceBatch(batches[i], cuda)
+            s.synchronize()
+            gate.wait(timeout=60)
+            for r in range(reps):
+                d.best_score.fill_(-7)
+                d.best_index.fill_(-7)
+                torch.cuda.current_stream().synchronize()
+                d.run(stream=s)
+                s.synchronize()
+                score, index = d.results()
+                if not (np.array_equal(score, wants[i][0]) and np.array_equal(index, wants[i][1])):
+                    bad.append((i, r))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=180)
+    assert not any(t.is_alive() for t in ts), "a worker did not finish"
+    assert not errors, errors
+    assert not bad, bad
