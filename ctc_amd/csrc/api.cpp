@@ -139,12 +139,14 @@ std::mutex g_perm_mu;
 std::map<std::string, PermCacheEntry> g_perm_cache;  // key: device|element size|extents|perm
 std::list<std::string> g_perm_lru;                   // most recently used first
 
-int get_permute_tables(int device, int rank, const int64_t *extents, const int *perm, int elem_size, PermuteTables &out)
+int get_permute_tables(int device, int rank, const int64_t *extents, const int *perm, int elem_size, PermuteTables &out,
+                       int out_row_modes = 0, int64_t out_row_pitch = 0)
 {
     std::string key = std::to_string(device) + "|" + std::to_string(elem_size) + "|";
     for (int i = 0; i < rank; ++i) key += std::to_string(extents[i]) + ",";
     key += "|";
     for (int i = 0; i < rank; ++i) key += std::to_string(perm[i]) + ",";
+    if (out_row_modes > 0) key += "|rows " + std::to_string(out_row_modes) + " pitch " + std::to_string(out_row_pitch);
     std::lock_guard<std::mutex> lock(g_perm_mu);
     auto it = g_perm_cache.find(key);
     if (it != g_perm_cache.end()) {
@@ -159,7 +161,7 @@ int get_permute_tables(int device, int rank, const int64_t *extents, const int *
         g_perm_lru.pop_back();
     }
     ctc::PermutePlan pp;
-    std::string e = ctc::plan_permute(rank, extents, perm, elem_size, pp);
+    std::string e = ctc::plan_permute(rank, extents, perm, elem_size, pp, out_row_modes, out_row_pitch);
     if (!e.empty()) return fail(CTC_TC_EINVAL, e);
     const std::vector<int64_t> *src[6] = {&pp.in_x, &pp.out_x, &pp.in_y, &pp.out_y, &pp.in_o, &pp.out_o};
     size_t total = 0, start[6];
@@ -407,6 +409,7 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
         }
         int wrc = grow_workspace(dt, sch.ws_bytes);
         if (wrc) return wrc;
+        pl->pads_zeroed.erase(device);  // partial sums overwrite what a padded-copy execution had cleared there
         e = ctc::launch_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, sch, dt.ws, stream);
         if (e != hipSuccess) return fail_hip(e, "contraction kernel launch");
         (void)hipEventRecord(dt.ws_done, stream);
@@ -477,6 +480,64 @@ int ensure_packed_plan(ctc_tc_plan *plan)
     return CTC_TC_OK;
 }
 
+// Plan::pad_transposes: the GEMM on the padded K-major copies.  Operand modes: batch, the M (N) modes in canonical
+// order, ONE contracted mode of extent k_padded (the contracted modes of the original, fused in A's order and
+// padded with zeros); C as the caller gave it, strides included.
+std::atomic<int> g_pad_transposes{1};          // 0: never (A/B runs)
+std::atomic<int64_t> g_padded_executions{0};  // since load, for tests
+int ensure_padded_plan(ctc_tc_plan *plan)
+{
+    const ctc::Plan &p = plan->plan;
+    std::lock_guard<std::mutex> lock(plan->mu);
+    if (plan->padded) return CTC_TC_OK;
+    char kname = 0;
+    for (const char *c = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ"; *c && !kname; ++c) {
+        bool used = false;
+        for (auto &m : p.modes) used = used || m.name == *c;
+        if (!used) kname = *c;
+    }
+    if (!kname) return fail(CTC_TC_EUNSUPPORTED, "no letter left for the fused contracted mode");
+    std::string sa, sb, sc, names;
+    std::vector<int64_t> ext;
+    auto add = [&](std::string &s, const std::vector<int> &ids) {
+        for (int id : ids) s.push_back(p.modes[id].name);
+    };
+    add(sa, p.canon_batch); add(sa, p.canon_m); sa.push_back(kname);
+    add(sb, p.canon_batch); add(sb, p.canon_n); sb.push_back(kname);
+    add(sc, p.c_modes);
+    for (auto &m : p.modes)
+        if (m.cls != ctc::kContracted) { names.push_back(m.name); ext.push_back(m.extent); }
+    names.push_back(kname);
+    ext.push_back(p.k_padded);
+    std::unique_ptr<ctc_tc_plan> q(new ctc_tc_plan());
+    std::string e = ctc::build_plan(sa + "," + sb + "->" + sc, (int)names.size(), names.data(), ext.data(), nullptr, nullptr,
+                                    p.strides_c.empty() ? nullptr : p.strides_c.data(), p.dtype, q->plan);
+    if (!e.empty()) return fail(CTC_TC_EINVAL, e);
+    plan->perm_bn.clear();
+    for (int id : p.canon_batch) plan->perm_bn.push_back(p.modes[id].pb);
+    for (int id : p.canon_n) plan->perm_bn.push_back(p.modes[id].pb);
+    for (int id : p.canon_k) plan->perm_bn.push_back(p.modes[id].pb);
+    plan->padded = std::move(q);
+    return CTC_TC_OK;
+}
+
+// bytes of the two padded copies
+struct PaddedBytes {
+    int64_t a, b;
+};
+PaddedBytes padded_bytes(const ctc::Plan &p)
+{
+    auto rows = [&](const std::vector<int> &ids) {
+        int64_t n = 1;
+        for (int id : p.canon_batch) n *= p.modes[id].extent;
+        for (int id : ids) n *= p.modes[id].extent;
+        return n;
+    };
+    const int64_t es = ctc::dtype_size(p.dtype);
+    auto pad = [](int64_t b) { return (b + 255) & ~int64_t(255); };
+    return {pad(rows(p.canon_m) * p.k_padded * es), pad(rows(p.canon_n) * p.k_padded * es)};
+}
+
 // extents of the three explicit transposes: A as given, B as given, [batch,M,N] in GEMM order
 struct TransposeShapes {
     std::vector<int64_t> ea, eb, eg;
@@ -498,6 +559,80 @@ TransposeShapes transpose_shapes(const ctc::Plan &p)
     t.eg = ext_of(gemm_order);
     return t;
 }
+
+// The workspace of the padded copies on `device`, grown and ordered like the split-K workspace; the elements
+// between a row's end and the next row are cleared once per workspace (the copies never write them, both
+// operands hold zeros there, so they add 0 x 0 to every sum).  Caller holds no lock.
+int padded_workspace(ctc_tc_plan *plan, int device, hipStream_t s, bool sync_clear, char *&wa, char *&wb)
+{
+    const PaddedBytes pb = padded_bytes(plan->plan);
+    std::lock_guard<std::mutex> lock(plan->mu);
+    DeviceTables &dt = plan->tables[device];
+    if (dt.ws_used && dt.ws_stream != s && !sync_clear) {
+        hipError_t e = hipStreamWaitEvent(s, dt.ws_done, 0);
+        if (e != hipSuccess) return fail_hip(e, "hipStreamWaitEvent");
+    }
+    int rc = grow_workspace(dt, (size_t)(pb.a + pb.b));
+    if (rc) return rc;
+    if (plan->pads_zeroed[device] != dt.ws) {
+        hipError_t e = sync_clear ? hipMemset(dt.ws, 0, (size_t)(pb.a + pb.b)) : hipMemsetAsync(dt.ws, 0, (size_t)(pb.a + pb.b), s);
+        if (e != hipSuccess) return fail_hip(e, "clearing the padded copies");
+        plan->pads_zeroed[device] = dt.ws;
+    }
+    wa = static_cast<char *>(dt.ws);
+    wb = wa + pb.a;
+    return CTC_TC_OK;
+}
+
+// tables of the two copies: A -> [batch, M, K | pad], B -> [batch, N, K | pad]
+int padded_permute_tables(ctc_tc_plan *plan, int device, PermuteTables &ta, PermuteTables &tb)
+{
+    const ctc::Plan &p = plan->plan;
+    const TransposeShapes ts = transpose_shapes(p);
+    const int es = (int)ctc::dtype_size(p.dtype), nk = (int)p.canon_k.size();
+    int rc = get_permute_tables(device, (int)ts.ea.size(), ts.ea.data(), p.perm_a.data(), es, ta, nk, p.k_padded);
+    if (rc) return rc;
+    return get_permute_tables(device, (int)ts.eb.size(), ts.eb.data(), plan->perm_bn.data(), es, tb, nk, p.k_padded);
+}
+
+// Plan::pad_transposes: copy A and B into padded K-major rows, multiply those, C in place.  Executions of one
+// plan are serialised on the host here and ordered on the device through the workspace's event.
+int execute_padded(ctc_tc_plan *plan, double alpha, const void *A, const void *B, double beta, void *C, hipStream_t s)
+{
+    int device = 0;
+    int rc = current_device(device);
+    if (rc) return rc;
+    rc = ensure_padded_plan(plan);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> serial(plan->transposes_mu);
+    char *wa = nullptr, *wb = nullptr;
+    rc = padded_workspace(plan, device, s, false, wa, wb);
+    if (rc) return rc;
+    PermuteTables ta, tb;
+    rc = padded_permute_tables(plan, device, ta, tb);
+    if (rc) return rc;
+    const int es = (int)ctc::dtype_size(plan->plan.dtype);
+    ctc::PermuteParams pa = ta.params, pbm = tb.params;
+    pa.in = A;
+    pa.out = wa;
+    pbm.in = B;
+    pbm.out = wb;
+    hipError_t e = ctc::launch_permute(es, pa, s);
+    if (e == hipSuccess) e = ctc::launch_permute(es, pbm, s);
+    if (e != hipSuccess) return fail_hip(e, "copy into padded rows");
+    rc = launch_plan(plan->padded.get(), alpha, wa, wb, beta, C, s);
+    {
+        std::lock_guard<std::mutex> lock(plan->mu);
+        DeviceTables &dt = plan->tables[device];
+        (void)hipEventRecord(dt.ws_done, s);
+        dt.ws_stream = s;
+        dt.ws_used = true;
+    }
+    if (rc == CTC_TC_OK) g_padded_executions.fetch_add(1);
+    return rc;
+}
+
+bool takes_padded_path(const ctc_tc_plan *plan) { return plan->plan.pad_transposes && g_pad_transposes.load() != 0; }
 
 }  // namespace
 
@@ -536,6 +671,10 @@ int ctc_tc_set_option(const char *name, int64_t value)
         ctc::dma_gemm_set_stream_k_group((int)value);
         return CTC_TC_OK;
     }
+    if (n == "pad_transposes") {
+        g_pad_transposes.store(value != 0);
+        return CTC_TC_OK;
+    }
     return fail(CTC_TC_EINVAL, "unknown option '" + n + "'");
 }
 
@@ -549,6 +688,8 @@ int64_t ctc_tc_get_option(const char *name)
     if (n == "dma_gemm") return g_dma_gemm.load();
     if (n == "stream_k") return ctc::dma_gemm_get_stream_k();
     if (n == "stream_k_group") return ctc::dma_gemm_get_stream_k_group();
+    if (n == "pad_transposes") return g_pad_transposes.load();
+    if (n == "padded_executions") return g_padded_executions.load();
     if (n == "launches_dma_gemm") return g_launches_dma_gemm.load();
     if (n == "launches_bf16_ring") return ctc::bf16_ring_launches();
     if (n == "launches_classic") return g_launches_classic.load();
@@ -629,7 +770,7 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
     case CTC_TC_Q_GEMM_DIMS: v = {p.M, p.N, p.K, p.batch}; break;
     case CTC_TC_Q_TILE:
         v = {p.tile.bm, p.tile.bn, p.tile.bk, p.tile.threads, p.layout_a, p.layout_b,
-             p.vec_a, p.vec_b, p.tile.group, p.kernel, p.vec_c};
+             p.vec_a, p.vec_b, p.tile.group, p.kernel, p.vec_c, p.prefer_transposes ? 1 : (p.pad_transposes ? 2 : 0)};
         break;
     case CTC_TC_Q_ROW_A: return copy_out(p.row_a, out, cap);
     case CTC_TC_Q_K_A: return copy_out(p.k_a, out, cap);
@@ -723,6 +864,19 @@ int ctc_tc_plan_prepare(ctc_tc_plan *plan)
         const size_t ttgt = (size_t)ctc_tc_ttgt_workspace_bytes(plan);
         if (ttgt > bytes) bytes = ttgt;
     }
+    if (takes_padded_path(plan)) {
+        // everything the padded-copy execution touches: the GEMM plan on the copies with its tables and split-K
+        // workspace, the two copies' tables, the workspace of the copies (cleared here)
+        rc = ensure_padded_plan(plan);
+        if (rc) return rc;
+        rc = ctc_tc_plan_prepare(plan->padded.get());
+        if (rc) return rc;
+        PermuteTables ta, tb;
+        rc = padded_permute_tables(plan, device, ta, tb);
+        if (rc) return rc;
+        char *wa = nullptr, *wb = nullptr;
+        return padded_workspace(plan, device, nullptr, true, wa, wb);
+    }
     if (bytes > 0) {
         std::lock_guard<std::mutex> lock(plan->mu);
         rc = grow_workspace(plan->tables[device], bytes);
@@ -771,6 +925,7 @@ int ctc_tc_execute(ctc_tc_plan *plan, double alpha, const void *A, const void *B
         dt.ws_used = true;
         return CTC_TC_OK;
     }
+    if (takes_padded_path(plan)) return execute_padded(plan, alpha, A, B, beta, C, static_cast<hipStream_t>(stream));
     return launch_plan(plan, alpha, A, B, beta, C, static_cast<hipStream_t>(stream));
     CTC_ABI_CATCH
 }

@@ -58,6 +58,11 @@ struct ctc_tc_plan {
     std::mutex mu;
     std::map<int, ctc_internal::DeviceTables> tables;  // by device ordinal
     std::unique_ptr<ctc_tc_plan> packed;  // GEMM on packed [batch,M,K] x [batch,K,N] operands (TTGT)
+    // GEMM on K-major rows [batch,M,Kp] x [batch,N,Kp] (Kp = Plan::k_padded, one fused contracted mode), C in
+    // place; perm_bn: the transpose of B into [batch,N,K]
+    std::unique_ptr<ctc_tc_plan> padded;
+    std::vector<int> perm_bn;
+    std::map<int, const void *> pads_zeroed;  // by device: the workspace whose pad columns have been cleared
     std::mutex transposes_mu;             // one execution through the internal transpose workspace at a time
 };
 

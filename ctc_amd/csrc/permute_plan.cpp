@@ -30,7 +30,8 @@ void offsets(const std::vector<int> &modes, const std::vector<int64_t> &ext,
 
 }  // namespace
 
-std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, int elem_size, PermutePlan &pl)
+std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, int elem_size, PermutePlan &pl,
+                         int out_row_modes, int64_t out_row_pitch)
 {
     pl = PermutePlan();
     if (rank <= 0 || rank > 32) return "bad rank";
@@ -45,6 +46,13 @@ std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, i
         total *= extents_in[p];
     }
     pl.total = total;
+    // padded output rows: the row part is the last out_row_modes output positions
+    if (out_row_modes < 0 || out_row_modes > rank) return "bad out_row_modes";
+    int64_t row_len = 1;
+    for (int p = rank - out_row_modes; p < rank; ++p) row_len *= extents_in[perm[p]];
+    const bool padded = out_row_modes > 0 && out_row_pitch != row_len;
+    if (padded && (out_row_pitch < row_len || out_row_pitch % V != 0 || row_len < 2))
+        return "out_row_pitch must be at least the row length (of 2 elements or more) and a multiple of a 16-byte vector";
 
     // 1. drop extent-1 modes
     std::vector<int> keep_id(rank, -1);
@@ -55,15 +63,22 @@ std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, i
             e1.push_back(extents_in[i]);
         }
     std::vector<int> q1;
+    std::vector<char> in_row1;  // per entry of q1: part of a padded output row
     for (int p = 0; p < rank; ++p)
-        if (keep_id[perm[p]] >= 0) q1.push_back(keep_id[perm[p]]);
+        if (keep_id[perm[p]] >= 0) {
+            q1.push_back(keep_id[perm[p]]);
+            in_row1.push_back(padded && p >= rank - out_row_modes);
+        }
 
-    // 2. fuse runs of input modes that stay adjacent and in order in the output
+    // 2. fuse runs of input modes that stay adjacent and in order in the output (never across the end of a
+    // padded row: the modes that count rows are not contiguous with the modes inside a row)
     std::vector<std::pair<int, int>> groups;  // [first, last] input mode of each output group
+    std::vector<char> group_in_row;
     for (size_t p = 0; p < q1.size();) {
         size_t e = p;
-        while (e + 1 < q1.size() && q1[e + 1] == q1[e] + 1) ++e;
+        while (e + 1 < q1.size() && q1[e + 1] == q1[e] + 1 && in_row1[e + 1] == in_row1[e]) ++e;
         groups.push_back({q1[p], q1[e]});
+        group_in_row.push_back(in_row1[p]);
         p = e + 1;
     }
     std::vector<int> order(groups.size());
@@ -88,6 +103,10 @@ std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, i
         for (int i = r - 1; i >= 0; --i) { si[i] = s; s *= ext[i]; }
         s = 1;
         for (int p = r - 1; p >= 0; --p) { so[q[p]] = s; s *= ext[q[p]]; }
+        // output group p is groups[p]; a group that counts rows steps by whole (padded) rows
+        if (padded)
+            for (int p = 0; p < r; ++p)
+                if (!group_in_row[(size_t)p]) so[q[p]] = so[q[p]] / row_len * out_row_pitch;
     }
 
     if (r >= 1) {

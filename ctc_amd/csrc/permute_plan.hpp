@@ -31,6 +31,11 @@ struct PermutePlan {
 };
 
 // out mode p = in mode perm[p]; both packed, last mode fastest.
-std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, int elem_size, PermutePlan &plan);
+// out_row_modes > 0: the last out_row_modes output modes form rows that lie out_row_pitch elements apart in the
+// output (out_row_pitch >= the rows' packed length, a multiple of a 16-byte vector); the slower output modes count
+// rows.  The elements between a row's end and the next row are not written.  `total` stays the number of elements
+// moved.
+std::string plan_permute(int rank, const int64_t *extents_in, const int *perm, int elem_size, PermutePlan &plan,
+                         int out_row_modes = 0, int64_t out_row_pitch = 0);
 
 }  // namespace ctc

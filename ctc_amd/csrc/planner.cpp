@@ -399,6 +399,27 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
                               packed(p.a_modes, p.strides_a) && packed(p.b_modes, p.strides_b) && packed(p.c_modes, p.strides_c);
     }
 
+    // Element loads under a large contraction (see Plan::pad_transposes).  Thresholds from tools/odd_extent_probe.py:
+    // the copies cost two passes over A and B at 3 - 4 TB/s, the GEMM gains 10 - 15 % in fp64 and 50 - 60 % in
+    // fp32 (whose element loads are 4 bytes wide); bf16 element loads run at a quarter of the vector kernels' rate.
+    {
+        auto packed = [&](const std::vector<int> &modes, const std::vector<int64_t> &strides) {
+            int64_t s = 1;
+            for (size_t i = modes.size(); i-- > 0;) {
+                if (strides[i] != s) return false;
+                s *= p.modes[modes[i]].extent;
+            }
+            return true;
+        };
+        static const bool off = getenv("CTC_TC_NO_PAD_TRANSPOSES") != nullptr;
+        const int64_t unit = 64 / dtype_size(dtype);
+        const int64_t min_mn = dtype == kF64 ? 2048 : 1024, min_k = dtype == kF64 ? 1024 : 512;
+        p.k_padded = (p.K + unit - 1) / unit * unit;
+        p.pad_transposes = !off && !p.prefer_transposes && (p.layout_a == kLayoutScalar || p.layout_b == kLayoutScalar) &&
+                           p.tile.bm >= 128 && p.M >= min_mn && p.N >= min_mn && p.K >= min_k &&
+                           packed(p.a_modes, p.strides_a) && packed(p.b_modes, p.strides_b);
+    }
+
     // Skinny path: a handful of output rows over a long N.  Needs 16-byte vectors along
     // an N mode in both B and C.
     p.kernel = kKernelGemm;
@@ -507,6 +528,9 @@ std::string describe(const Plan &p)
     o << "\n";
     o << "tile " << p.tile.bm << "x" << p.tile.bn << "x" << p.tile.bk << " threads " << p.tile.threads
       << " group " << p.tile.group << "\n";
+    o << "transposes " << (p.prefer_transposes ? "explicit (A, B, C)" : p.pad_transposes ? "A and B into padded K-major rows" : "fused into the loads");
+    if (p.pad_transposes) o << " of " << p.k_padded;
+    o << "\n";
     return o.str();
 }
 

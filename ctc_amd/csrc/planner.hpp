@@ -80,6 +80,12 @@ struct Plan {
     // The fused kernel would read all three tensors element by element at a stride (a batch mode is their
     // unit-stride mode): ctc_tc_execute transposes the operands explicitly instead (packed operands, beta == 0).
     bool prefer_transposes = false;
+    // An operand would be read element by element (an odd extent on its unit-stride mode) under a contraction
+    // large enough to pay for two passes over A and B: ctc_tc_execute first copies both into K-major rows
+    // [batch, M, K] / [batch, N, K] whose length is padded to k_padded (a multiple of 64 bytes, zero-filled),
+    // so that the GEMM kernel with LDS-DMA staging runs on them; C is written in place (any alpha, beta).
+    bool pad_transposes = false;
+    int64_t k_padded = 0;
     int64_t sk_X = 1, sk_Y = 1, sk_O = 1;
     std::vector<int64_t> sk_bx, sk_cx, sk_by, sk_cy, sk_bo, sk_co;
 

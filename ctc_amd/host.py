@@ -131,7 +131,7 @@ class Plan:
         return "".join(names[i] for i in self.get(query))
 
     def summary(self):
-        bm, bn, bk, threads, la, lb, va, vb, group, kernel, vc = self.get(_lib.Q_TILE)
+        bm, bn, bk, threads, la, lb, va, vb, group, kernel, vc, transposes = self.get(_lib.Q_TILE)
         m, n, k, batch = self.get(_lib.Q_GEMM_DIMS)
         return {
             "names": self.names,
@@ -147,6 +147,7 @@ class Plan:
             "tile": (bm, bn, bk), "threads": threads,
             "layout_a": LAYOUT_NAMES[la], "layout_b": LAYOUT_NAMES[lb], "vec_a": va, "vec_b": vb, "vec_c": vc,
             "group": group, "kernel": KERNEL_NAMES[kernel],
+            "transposes": ("fused", "explicit", "padded_copies")[transposes],
         }
 
     @property

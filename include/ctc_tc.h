@@ -81,7 +81,11 @@ enum ctc_tc_query {
     CTC_TC_Q_EXEC_N = 13,
     CTC_TC_Q_EXEC_K = 14,
     CTC_TC_Q_GEMM_DIMS = 15,   /* {M, N, K, batch} */
-    CTC_TC_Q_TILE = 16,        /* {BM, BN, BK, threads, layoutA, layoutB, vecA, vecB, group, kernel, vecC} */
+    CTC_TC_Q_TILE = 16,        /* {BM, BN, BK, threads, layoutA, layoutB, vecA, vecB, group, kernel, vecC, transposes:
+                                  0 the permutation is fused into the operand loads, 1 ctc_tc_execute transposes A, B and
+                                  C explicitly (a batch mode is the unit-stride mode of all three), 2 it copies A and B
+                                  into padded K-major rows first (an operand would be read element by element under a
+                                  large contraction) and writes C in place} */
     /* element-offset tables of the execution view: address of GEMM element
      * A(m,k) = A + ROW_A[m] + K_A[k] (+ BAT_A[b]), and so on */
     CTC_TC_Q_ROW_A = 17,
@@ -150,14 +154,17 @@ const char *ctc_tc_last_error(void);
  *                   into equal K chunks or the K-tile iterations of the last one to two rounds dealt out in
  *                   equal shares (stream-K); 1: never shares; 2: shares whenever the launch allows;
  *   "stream_k_group" consecutive tiles whose shares walk K together (1 .. 64); 0 (default): 16, or 8 where that
- *                   leaves less padding.
+ *                   leaves less padding;
+ *   "pad_transposes" 1 (default): a plan whose CTC_TC_Q_TILE reports transposes = 2 runs through the padded copies;
+ *                   0: it runs the fused kernel with element loads (A/B runs).
  * No reference counterpart.
  */
 int ctc_tc_set_option(const char *name, int64_t value);
 /* Value of a knob above, or of a read-only counter of tiled-GEMM launches since the library was loaded:
  * "launches_classic" (register-staged), "launches_dma_gemm", "launches_stream" (persistent,
  * register-staged), "launches_stream_f64_dma", "launches_bf16_ring" (the bf16 256-tile ring kernel, a
- * subset of "launches_classic").
+ * subset of "launches_classic"), "padded_executions" (executions that went through the padded copies; their GEMM
+ * counts in the launch counters as well).
  * Negative ctc_tc_status for an unknown name. */
 int64_t ctc_tc_get_option(const char *name);
 

@@ -25,7 +25,7 @@ static std::mt19937_64 rng;
 static int pick(std::initializer_list<int> v) { return *(v.begin() + rng() % v.size()); }
 static int64_t val(int64_t i, int salt) { return (int64_t)((i * 7 + salt) % 11) - 5; }
 
-static int failures = 0, ran_contractions = 0, ran_shards = 0, ran_permutations = 0, took_skinny = 0, took_vec = 0;
+static int failures = 0, ran_contractions = 0, ran_shards = 0, ran_permutations = 0, ran_padded = 0, took_skinny = 0, took_vec = 0;
 #define EXPECT(cond, ...)                        \
     do {                                         \
         if (!(cond)) {                           \
@@ -261,19 +261,30 @@ static void one_permutation(int n)
     for (int i = 0; i < rank; ++i) perm[(size_t)i] = i;
     std::shuffle(perm.begin(), perm.end(), rng);
     const int es = pick({2, 4, 8});
+    // every other case: the last few output modes form rows that lie a padded pitch apart
+    int row_modes = 0;
+    int64_t row_len = 1, pitch = 0;
+    if (rng() % 2) {
+        row_modes = 1 + (int)(rng() % (unsigned)rank);
+        for (int p = rank - row_modes; p < rank; ++p) row_len *= ext[(size_t)perm[(size_t)p]];
+        const int64_t V = 16 / es;
+        pitch = (row_len + V - 1) / V * V + V * (int64_t)(rng() % 3);
+        if (row_len < 2) row_modes = 0;
+    }
     ctc::PermutePlan pp;
-    std::string err = ctc::plan_permute(rank, ext.data(), perm.data(), es, pp);
-    const std::string what = "permutation #" + std::to_string(n);
+    std::string err = ctc::plan_permute(rank, ext.data(), perm.data(), es, pp, row_modes, row_modes ? pitch : 0);
+    const std::string what = "permutation #" + std::to_string(n) + (row_modes ? " (padded rows)" : "");
     EXPECT(err.empty(), "%s: %s", what.c_str(), err.c_str());
     EXPECT(pp.total == total && pp.X * pp.Y * pp.O == total, "%s: sizes", what.c_str());
+    const int64_t rows = total / row_len, out_span = row_modes ? (rows - 1) * pitch + row_len : total;
     // out[out offset] = in[in offset] for every (x, y, o) must be the permutation
-    std::vector<int64_t> out((size_t)total, -1);
+    std::vector<int64_t> out((size_t)out_span, -1);
     for (int64_t o = 0; o < pp.O; ++o)
         for (int64_t y = 0; y < pp.Y; ++y)
             for (int64_t x = 0; x < pp.X; ++x) {
                 const int64_t i = pp.in_x.at((size_t)x) + pp.in_y.at((size_t)y) + pp.in_o.at((size_t)o);
                 const int64_t j = pp.out_x.at((size_t)x) + pp.out_y.at((size_t)y) + pp.out_o.at((size_t)o);
-                EXPECT(i >= 0 && i < total && j >= 0 && j < total, "%s: offset outside the tensor", what.c_str());
+                EXPECT(i >= 0 && i < total && j >= 0 && j < out_span, "%s: offset outside the tensor", what.c_str());
                 EXPECT(out[(size_t)j] == -1, "%s: an output element written twice", what.c_str());
                 out[(size_t)j] = i;
             }
@@ -285,13 +296,20 @@ static void one_permutation(int n)
     for (int64_t j = 0; j < total; ++j) {
         int64_t i = 0;
         for (int d = 0; d < rank; ++d) i += idx[(size_t)d] * in_stride[(size_t)perm[(size_t)d]];
-        EXPECT(out[(size_t)j] == i, "%s: element %lld comes from %lld, expected %lld", what.c_str(), (long long)j, (long long)out[(size_t)j], (long long)i);
+        const int64_t at = row_modes ? (j / row_len) * pitch + j % row_len : j;  // packed output index j -> padded offset
+        EXPECT(out[(size_t)at] == i, "%s: element %lld comes from %lld, expected %lld", what.c_str(), (long long)j, (long long)out[(size_t)at], (long long)i);
         for (int d = rank - 1; d >= 0; --d) {
             if (++idx[(size_t)d] < oext[(size_t)d]) break;
             idx[(size_t)d] = 0;
         }
     }
+    // contiguous-run claims: the first in_run entries of the x table step by one in the input, the first out_run
+    // entries of the y (or, with a common fastest mode, x) table step by one in the output
+    const std::vector<int64_t> &oy = pp.same_fast ? pp.out_x : pp.out_y;
+    for (int64_t k = 1; k < pp.in_run && k < (int64_t)pp.in_x.size(); ++k) EXPECT(pp.in_x[(size_t)k] == pp.in_x[0] + k, "%s: in_run", what.c_str());
+    for (int64_t k = 1; k < pp.out_run && k < (int64_t)oy.size(); ++k) EXPECT(oy[(size_t)k] == oy[0] + k, "%s: out_run", what.c_str());
     ++ran_permutations;
+    ran_padded += row_modes > 0;
 }
 
 int main(int argc, char **argv)
@@ -309,7 +327,7 @@ int main(int argc, char **argv)
         const int64_t e[4] = {2, 3, 4, 5};
         (void)ctc::build_plan(s, 4, "abcd", e, nullptr, nullptr, nullptr, 0, p);
     }
-    printf("%d contractions (%d with a vector layout, %d on the skinny kernels), %d shards, %d permutations: %d failures\n", ran_contractions, took_vec,
-           took_skinny, ran_shards, ran_permutations, failures);
+    printf("%d contractions (%d with a vector layout, %d on the skinny kernels), %d shards, %d permutations (%d with padded rows): %d failures\n", ran_contractions, took_vec,
+           took_skinny, ran_shards, ran_permutations, ran_padded, failures);
     return failures ? 1 : 0;
 }
