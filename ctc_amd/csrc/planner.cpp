@@ -413,7 +413,10 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
         };
         static const bool off = getenv("CTC_TC_NO_PAD_TRANSPOSES") != nullptr;
         const int64_t unit = 64 / dtype_size(dtype);
-        const int64_t min_mn = dtype == kF64 ? 2048 : 1024, min_k = dtype == kF64 ? 1024 : 512;
+        // CTC_TC_PAD_MIN_MN / CTC_TC_PAD_MIN_K: calibration knobs
+        static const int64_t env_mn = getenv("CTC_TC_PAD_MIN_MN") ? atoll(getenv("CTC_TC_PAD_MIN_MN")) : 0;
+        static const int64_t env_k = getenv("CTC_TC_PAD_MIN_K") ? atoll(getenv("CTC_TC_PAD_MIN_K")) : 0;
+        const int64_t min_mn = env_mn > 0 ? env_mn : (dtype == kF64 ? 2048 : 1024), min_k = env_k > 0 ? env_k : (dtype == kF64 ? 1024 : 512);
         p.k_padded = (p.K + unit - 1) / unit * unit;
         p.pad_transposes = !off && !p.prefer_transposes && (p.layout_a == kLayoutScalar || p.layout_b == kLayoutScalar) &&
                            p.tile.bm >= 128 && p.M >= min_mn && p.N >= min_mn && p.K >= min_k &&

@@ -389,6 +389,7 @@ def test_batch_fastest_layouts_take_the_transposes(cuda, oracle, spec, ext, dtyp
     for rep in range(3):
         dC = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
         if rep == 2:
+            torch.cuda.synchronize()  # the fill ran on the default stream: s2 must not overtake it
             with torch.cuda.stream(s2):
                 plan.execute(dA, dB, dC, alpha=1.5, stream=s2.cuda_stream)
             s2.synchronize()

@@ -38,6 +38,7 @@ def test_one_plan_many_threads_and_streams(cuda, prepared):
     if prepared:
         plan.prepare()
     outs = [torch.full((n ** 4,), float("nan"), dtype=torch.float64, device=cuda) for _ in range(threads)]
+    torch.cuda.synchronize()  # the fills ran on the default stream: the workers' streams must not overtake them
     gate = threading.Barrier(threads)
     errors = []
 

@@ -25,6 +25,7 @@ def test_noalloc_replays_from_a_captured_graph(cuda, n, dtype):
     plan.execute(A, B, want)
     got = torch.full((n ** 4,), float("nan"), dtype=tdt, device=cuda)
     side = torch.cuda.Stream()
+    torch.cuda.synchronize()  # the fills above ran on the default stream: the side stream must not overtake them
     with torch.cuda.stream(side):
         plan.execute_noalloc(A, B, got)  # once outside capture: every lazily cached query has been made
         side.synchronize()

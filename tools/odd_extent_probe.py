@@ -1,7 +1,8 @@
-"""Odd extents: the fused kernel (element loads) against what a pad-and-transpose path could reach:
-both operands brought to K-major rows [.., K padded to a multiple of 8] (the LDS-DMA kernel qualifies), C written
-in place through the offset tables.  Times the GEMM part on the padded operands and the two transposes (packed
-output, which is what the permutation kernels produce today) separately.  One JSON line per extent."""
+"""Odd extents (no 16-byte vectors are legal on the operands): the headline contraction through the padded copies
+(the automatic choice for large problems) against the fused kernel with element loads on the same plan
+("pad_transposes" option off).  One JSON line per (element type, extent).
+
+  python tools/odd_extent_probe.py [extents ...]"""
 import json
 import os
 import statistics
@@ -13,6 +14,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import ctc_amd  # noqa: E402
+
+PEAK = {"f64": 78.6, "f32": 157.3, "bf16": 2500.0}
 
 
 def timed(fn, iters=8, seconds=0.1):
@@ -32,42 +35,36 @@ def timed(fn, iters=8, seconds=0.1):
 
 
 def main():
+    extents = [int(x) for x in sys.argv[1:]] or [33, 37, 41, 45, 49, 55, 63, 65, 75, 81, 95]
     dev = torch.device("cuda:0")
-    for dtype, tdt, unit in (("f64", torch.float64, 8), ("f32", torch.float32, 16)):
-        for n in (63, 65, 75, 81, 95):
+    for dtype, tdt in (("f64", torch.float64), ("f32", torch.float32), ("bf16", torch.bfloat16)):
+        for n in extents:
             ext = dict(a=n, b=n, i=n, j=n, e=n, m=n)
-            A = torch.empty(n ** 4, dtype=tdt, device=dev)
-            B = torch.empty(n ** 4, dtype=tdt, device=dev)
-            C = torch.empty(n ** 4, dtype=tdt, device=dev)
+            A = torch.zeros(n ** 4, dtype=torch.float32, device=dev)
+            B = torch.zeros(n ** 4, dtype=torch.float32, device=dev)
             ctc_amd.fill(A, 1)
             ctc_amd.fill(B, 2)
-            fused = ctc_amd.Plan("aeim,ebmj->abij", ext, dtype)
-            t_fused = timed(lambda: fused.execute(A, B, C))
-            K = n * n
-            Kp = (K + unit - 1) // unit * unit
-            A2 = torch.zeros(n * n * Kp, dtype=tdt, device=dev)
-            B2 = torch.zeros(n * n * Kp, dtype=tdt, device=dev)
-            A2.view(n, n, Kp)[:, :, :K] = A.view(n, n, n, n).permute(0, 2, 1, 3).reshape(n, n, K)       # [a,i,(e,m)]
-            B2.view(n, n, Kp)[:, :, :K] = B.view(n, n, n, n).permute(1, 3, 0, 2).reshape(n, n, K)       # [b,j,(e,m)]
+            A, B = A.to(tdt), B.to(tdt)
+            C1 = torch.empty(n ** 4, dtype=tdt, device=dev)
             C2 = torch.empty(n ** 4, dtype=tdt, device=dev)
-            gemm = ctc_amd.Plan("aik,bjk->abij", dict(a=n, b=n, i=n, j=n, k=Kp), dtype)
-            names = ("launches_classic", "launches_dma_gemm")
-            before = [ctc_amd.get_option(x) for x in names]
-            t_gemm = timed(lambda: gemm.execute(A2, B2, C2))
-            took = [x[9:] for x, b in zip(names, before) if ctc_amd.get_option(x) > b]
-            diff = float((C2 - C).abs().max() / C.abs().max())
-            At = torch.empty(n ** 4, dtype=tdt, device=dev)
-            t_pa = timed(lambda: ctc_amd.permute(A.view(n, n, n, n), (0, 2, 1, 3), out=At.view(n, n, n, n)))
-            t_pb = timed(lambda: ctc_amd.permute(B.view(n, n, n, n), (1, 3, 0, 2), out=At.view(n, n, n, n)))
+            plan = ctc_amd.Plan("aeim,ebmj->abij", ext, dtype)
+            s = plan.summary()
+            plan.prepare()
             flops = 2.0 * n ** 6
-            total = t_gemm + t_pa + t_pb
-            print(json.dumps({"dtype": dtype, "extent": n, "fused_ms": round(t_fused, 4), "fused_tflops": round(flops / t_fused * 1e-9, 2),
-                              "padded_gemm_ms": round(t_gemm, 4), "padded_gemm_tflops": round(flops / t_gemm * 1e-9, 2), "gemm_kernel": took,
-                              "transpose_a_ms": round(t_pa, 4), "transpose_b_ms": round(t_pb, 4),
-                              "transposes_TBps": round(2 * 2 * n ** 4 * A.element_size() / (t_pa + t_pb) * 1e-9, 2),
-                              "pad_path_ms": round(total, 4), "pad_path_tflops": round(flops / total * 1e-9, 2),
-                              "pad_path_over_fused": round(t_fused / total, 3), "max_rel_diff": diff}), flush=True)
-            del A, B, C, A2, B2, C2, At
+            ctc_amd.set_option("pad_transposes", 0)
+            t_fused = timed(lambda: plan.execute(A, B, C1))
+            ctc_amd.set_option("pad_transposes", 1)
+            line = {"dtype": dtype, "extent": n, "automatic": s["transposes"], "tile": list(s["tile"]),
+                    "fused_ms": round(t_fused, 4), "fused_tflops": round(flops / t_fused * 1e-9, 2),
+                    "fused_frac_of_peak": round(flops / t_fused * 1e-9 / PEAK[dtype], 3)}
+            if s["transposes"] == "padded_copies":
+                t_pad = timed(lambda: plan.execute(A, B, C2))
+                line.update({"padded_ms": round(t_pad, 4), "padded_tflops": round(flops / t_pad * 1e-9, 2),
+                             "padded_frac_of_peak": round(flops / t_pad * 1e-9 / PEAK[dtype], 3),
+                             "padded_over_fused": round(t_fused / t_pad, 3),
+                             "max_rel_diff": float((C2.double() - C1.double()).abs().max() / C1.double().abs().max())})
+            print(json.dumps(line), flush=True)
+            del A, B, C1, C2, plan
             torch.cuda.empty_cache()
 
 
