@@ -2,7 +2,7 @@
 packed GEMM views, torch.einsum (transposes + batched GEMM + transpose) on the contractions themselves.
 A measurement only: nothing in the library calls either.  One JSON line per case.
 
-  python tools/vendor_gemm_cmp.py [f64] [f32] [bf16] [config4]
+  python tools/vendor_gemm_cmp.py [f64] [f32] [bf16] [config4] [odd]
 """
 import json
 import os
@@ -111,7 +111,7 @@ def contraction(dtype, spec, ext, iters=10):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f64", "f32", "bf16", "config4"]
+    which = sys.argv[1:] or ["f64", "f32", "bf16", "config4", "odd"]
     torch.cuda.set_device(0)
     print(json.dumps({"torch": torch.__version__, "hip": torch.version.hip, "device": torch.cuda.get_device_name(0)}), flush=True)
     head = "aeim,ebmj->abij"
@@ -125,5 +125,9 @@ if __name__ == "__main__":
             gemm(w, 8192, 8192, 8192, False)
             gemm(w, 8192, 8192, 8192, True)
             contraction(w, head, dict(a=96, b=96, i=96, j=96, e=96, m=96))
+        elif w == "odd":
+            for dt in ("f64", "f32", "bf16"):
+                for n in (63, 75, 95):
+                    contraction(dt, head, dict(a=n, b=n, i=n, j=n, e=n, m=n), iters=8)
         elif w == "config4":
             contraction("f64", "adij,bcdk->abcijk", dict(a=5, b=40, c=40, i=40, j=40, k=40, d=64), iters=6)
