@@ -125,3 +125,34 @@ def test_small_or_even_contractions_keep_the_fused_kernel():
     # explicit strides (not packed): the copies assume packed operands
     p = ctc_amd.Plan("ak,kb->ab", dict(a=2049, b=2051, k=1025), "f64", strides_a=[1027, 1])
     assert p.summary()["transposes"] == "fused"
+
+
+def test_seeded_random_mode_orders_through_the_padded_copies(cuda, oracle):
+    """Random mode orders of A, B and C (so: random transposes into the padded rows, role swaps, C layouts), odd
+    extents, all three element types, alpha and beta.  Cases the planner leaves on the fused kernel (an operand
+    order that happens to allow vectors) are checked all the same; most must take the padded copies."""
+    import random
+    rng = random.Random(0x0DD)
+    took = 0
+    n_cases = 14
+    for n in range(n_cases):
+        dtype = rng.choice(["f64", "f32", "f32", "bf16"])
+        ext = dict(a=rng.choice([47, 49, 51]), i=rng.choice([47, 49, 51]), b=rng.choice([47, 49, 51]), j=rng.choice([47, 49, 51]),
+                   e=rng.choice([21, 23, 25]), m=rng.choice([47, 49, 51]))
+        la, lb, lc = list("aeim"), list("ebmj"), list("abij")
+        for m in (la, lb, lc):
+            rng.shuffle(m)
+        spec = "%s,%s->%s" % ("".join(la), "".join(lb), "".join(lc))
+        alpha, beta = rng.choice([1.0, -0.5, 2.0]), rng.choice([0.0, 0.0, 1.0, -1.5])
+        num = lambda t: int(np.prod([ext[c] for c in t]))  # noqa: E731
+        A, B = oracle.fill(num(la), 100 + n, CODE[dtype]), oracle.fill(num(lb), 200 + n, CODE[dtype])
+        C0 = oracle.fill(num(lc), 300 + n, CODE[dtype])
+        plan = ctc_amd.Plan(spec, ext, dtype)
+        before = ctc_amd.get_option("padded_executions")
+        dC = _dev(C0.copy(), dtype, cuda)
+        plan.execute(_dev(A, dtype, cuda), _dev(B, dtype, cuda), dC, alpha=alpha, beta=beta)
+        took += ctc_amd.get_option("padded_executions") - before
+        want = _want(oracle, spec, ext, A, B, C0, alpha, beta, dtype)
+        got = _host(dC, dtype, oracle)
+        assert np.abs(got - want).max() <= 2 * TOL[dtype] * np.abs(want).max(), (n, spec, ext, dtype, alpha, beta, plan.summary()["transposes"])
+    assert took >= n_cases // 2, took
