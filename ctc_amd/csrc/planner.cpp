@@ -418,7 +418,14 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
         static const int64_t env_k = getenv("CTC_TC_PAD_MIN_K") ? atoll(getenv("CTC_TC_PAD_MIN_K")) : 0;
         const int64_t min_mn = env_mn > 0 ? env_mn : (dtype == kF64 ? 2048 : 1024), min_k = env_k > 0 ? env_k : (dtype == kF64 ? 1024 : 512);
         p.k_padded = (p.K + unit - 1) / unit * unit;
-        p.pad_transposes = !off && !p.prefer_transposes && (p.layout_a == kLayoutScalar || p.layout_b == kLayoutScalar) &&
+        // bf16 also when the k tables are affine in groups shorter than 16 only (the fastest contracted mode's
+        // extent is no multiple of 16): the ring kernel (K-tiles of 32, one table entry per tile or half tile) cannot
+        // take the operands as they are, and one fused contracted mode is affine throughout
+        // (measured on the headline contraction, tools/bf16_groups_probe.py: extent 56 loses 16 %, 72 / 88 / 104 gain
+        // 4 / 12 / 28 %: hence the larger size)
+        const bool bf16_short_groups = dtype == kBF16 && !p.k32_affine && !p.k16_affine && p.M >= 4096 && p.N >= 4096 &&
+                                       p.K >= 4096 && getenv("CTC_TC_NO_PAD_BF16_GROUPS") == nullptr;
+        p.pad_transposes = !off && !p.prefer_transposes && (p.layout_a == kLayoutScalar || p.layout_b == kLayoutScalar || bf16_short_groups) &&
                            p.tile.bm >= 128 && p.M >= min_mn && p.N >= min_mn && p.K >= min_k &&
                            packed(p.a_modes, p.strides_a) && packed(p.b_modes, p.strides_b);
     }
