@@ -402,6 +402,7 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
     // Element loads under a large contraction (see Plan::pad_transposes).  Thresholds from tools/odd_extent_probe.py:
     // the copies cost two passes over A and B at 3 - 4 TB/s, the GEMM gains 10 - 15 % in fp64 and 50 - 60 % in
     // fp32 (whose element loads are 4 bytes wide); bf16 element loads run at a quarter of the vector kernels' rate.
+    // Problems on the small tile lose 10 - 30 % with the copies and keep the fused kernel.
     {
         auto packed = [&](const std::vector<int> &modes, const std::vector<int64_t> &strides) {
             int64_t s = 1;
