@@ -22,14 +22,19 @@ def _operands(n, dtype, dev):
     return A, B
 
 
-@pytest.mark.parametrize("prepared", [False, True])
-def test_one_plan_many_threads_and_streams(cuda, prepared):
-    n, threads, reps = 48, 6, 8   # 2304^3: the last round of tiles is cut along K, so every launch uses the workspace
+@pytest.mark.parametrize("prepared,n", [(False, 48), (True, 48), (False, 49), (True, 49)])
+def test_one_plan_many_threads_and_streams(cuda, prepared, n):
+    threads, reps = 6, 8
+    # extent 48 (2304^3): the last round of tiles is cut along K, so every launch uses the plan's workspace;
+    # extent 49: odd, every execution copies A and B into the plan's padded workspace first (serialised per plan)
     A, B = _operands(n, torch.float64, cuda)
     ext = dict(a=n, b=n, i=n, j=n, e=n, m=n)
     ref_plan = ctc_amd.Plan(SPEC, ext, "f64")
     ref_plan.prepare()
-    assert ref_plan.schedule()["workspace_bytes"] > 0
+    if n % 2:
+        assert ref_plan.summary()["transposes"] == "padded_copies"
+    else:
+        assert ref_plan.schedule()["workspace_bytes"] > 0
     want = torch.empty(n ** 4, dtype=torch.float64, device=cuda)
     ref_plan.execute(A, B, want)
     torch.cuda.synchronize()
