@@ -448,10 +448,13 @@ def main():
 
     out = None
     if rank == 0:
-        s = plan.summary()
-        # which tiled-GEMM kernel the timed launches took (the library counts them and reports the form)
+        # the plan whose GEMM the launches ran (the plan itself unless it goes through copies of its operands: odd
+        # extents) and which tiled-GEMM kernel they took (the library counts them and reports the form)
+        gemm = plan.gemm_plan()
+        s = gemm.summary()
+        s["transposes"] = plan.summary()["transposes"]
         took = [c for c, b in zip(counters, launches_before) if ctc_amd.get_option(c) > b]
-        name, tile = plan.gemm_kernel_name()
+        name, tile = gemm.gemm_kernel_name()
         if took == ["launches_dma_gemm"] or took == ["launches_classic"]:
             s["kernel_name"], s["kernel_tile"] = name, tile
         else:
@@ -475,7 +478,7 @@ def main():
                     n, "" if world == 1 else ", the same contraction split along the free index a over %d GPUs "
                                              "(%d each), no collective" % (world, a_loc)),
                 "gemm_view_per_gpu": {"M": s["M"], "N": s["N"], "K": s["K"]},
-                "tile": s["kernel_tile"], "layout_a": s["layout_a"], "layout_b": s["layout_b"],
+                "tile": s["kernel_tile"], "layout_a": s["layout_a"], "layout_b": s["layout_b"], "operand_copies": s["transposes"],
                 "flops_per_step": flops_job,
                 "pct_of_fp64_mfma_peak": round(100.0 * value / (PEAK_FP64_MFMA_TFLOPS * world), 2),
                 "variants": {},

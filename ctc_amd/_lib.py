@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CTC_TC_LIB") or os.path.join(_HERE, "lib", "libctc_tc
 SYMBOLS = (
     "ctc_tc_version", "ctc_tc_last_error", "ctc_tc_device_count",
     "ctc_tc_plan_create", "ctc_tc_plan_destroy", "ctc_tc_plan_describe", "ctc_tc_plan_get",
-    "ctc_tc_plan_shard", "ctc_tc_plan_prepare", "ctc_tc_execute", "ctc_tc_permute",
+    "ctc_tc_plan_shard", "ctc_tc_plan_gemm_plan", "ctc_tc_plan_prepare", "ctc_tc_execute", "ctc_tc_permute",
     "ctc_tc_ttgt_workspace_bytes", "ctc_tc_execute_ttgt", "ctc_tc_fill", "ctc_tc_time_execute", "ctc_tc_time_execute_each",
     "ctc_tc_grouped_contract", "ctc_tc_execute_noalloc", "ctc_tc_noalloc_scratch_bytes", "ctc_tc_set_option", "ctc_tc_get_option",
 )
@@ -77,6 +77,8 @@ def load():
     L.ctc_tc_plan_describe.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
     L.ctc_tc_plan_get.restype = ctypes.c_int64
     L.ctc_tc_plan_get.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int64]
+    L.ctc_tc_plan_gemm_plan.restype = vp
+    L.ctc_tc_plan_gemm_plan.argtypes = [vp]
     L.ctc_tc_plan_shard.restype = ctypes.c_int
     L.ctc_tc_plan_shard.argtypes = [vp, ctypes.c_char, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp),
                                     i64p, i64p, i64p]

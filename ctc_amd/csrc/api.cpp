@@ -833,6 +833,22 @@ int ctc_tc_plan_shard(const ctc_tc_plan *plan, char mode, int rank, int nranks, 
     CTC_ABI_CATCH
 }
 
+ctc_tc_plan *ctc_tc_plan_gemm_plan(ctc_tc_plan *plan)
+{
+    try {
+        if (!plan) {
+            fail(CTC_TC_EINVAL, "null plan");
+            return nullptr;
+        }
+        if (plan->plan.prefer_transposes) return ensure_packed_plan(plan) == CTC_TC_OK ? plan->packed.get() : nullptr;
+        if (takes_padded_path(plan)) return ensure_padded_plan(plan) == CTC_TC_OK ? plan->padded.get() : nullptr;
+        return plan;
+    } catch (const std::exception &e) {
+        fail(CTC_TC_ENOMEM, std::string("building the GEMM plan: ") + e.what());
+        return nullptr;
+    }
+}
+
 int ctc_tc_plan_prepare(ctc_tc_plan *plan)
 {
     CTC_ABI_TRY

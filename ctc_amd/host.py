@@ -177,6 +177,18 @@ class Plan:
             return name, [128, 128, nsub * rb // DTYPE_SIZE[self.dtype]]
         return ("gemm_kernel<%s>" % ctype if ctype else "gemm_bf16_kernel"), list(s["tile"])
 
+    def gemm_plan(self):
+        """The plan whose tiled GEMM execute() launches: this plan, or the sub-plan it owns when it runs through
+        explicit transposes or padded copies (summary()["transposes"])."""
+        h = self._lib.ctc_tc_plan_gemm_plan(self._h)
+        if not h:
+            check(-1)
+        if h == self._h.value:
+            return self
+        sub = Plan(self.spec, self.extents, self.dtype, _handle=ctypes.c_void_p(h), _owned=False)
+        sub._parent = self  # the handle lives as long as its owner
+        return sub
+
     # ---- sharding ----------------------------------------------------------
     def shard(self, mode, rank, nranks):
         """Sub-plan for slab `rank` of `nranks` along `mode`, plus element offsets into A, B, C."""

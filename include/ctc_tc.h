@@ -193,6 +193,13 @@ int ctc_tc_plan_describe(const ctc_tc_plan *plan, char *buf, size_t buflen);
  * (negative on error). */
 int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_t cap);
 
+/* The plan whose tiled GEMM ctc_tc_execute launches for `plan`: `plan` itself, or the sub-plan it owns when it runs
+ * through explicit transposes or padded copies (CTC_TC_Q_TILE's transposes 1 / 2; built here on first use, host
+ * only).  CTC_TC_Q_SCHEDULE of `plan` describes the fused kernel (what ctc_tc_execute_noalloc launches);
+ * CTC_TC_Q_SCHEDULE of the returned plan describes the GEMM behind the copies.  Owned by `plan`: do not destroy.
+ * NULL on failure.  No reference counterpart. */
+ctc_tc_plan *ctc_tc_plan_gemm_plan(ctc_tc_plan *plan);
+
 /*
  * Plan for one shard of a contraction split along `mode` into nranks equal
  * contiguous slabs (extent must divide evenly).  Element offsets of the slab

@@ -124,3 +124,21 @@ def test_alignment_batches_are_validated_before_upload():
         b[key] = value
         with pytest.raises(ValueError, match=msg):
             DeviceAlignmentBatch(b, "cpu")
+
+
+def test_gemm_plan_is_the_plan_or_the_sub_plan_behind_the_copies():
+    even = ctc_amd.Plan(SPEC, dict(a=48, b=48, i=48, j=48, e=48, m=48), "f64")
+    assert even.gemm_plan() is even
+    odd = ctc_amd.Plan(SPEC, dict(a=49, b=49, i=49, j=49, e=49, m=49), "f64")
+    assert odd.summary()["transposes"] == "padded_copies"
+    sub = odd.gemm_plan()
+    s = sub.summary()
+    assert sub is not odd and (s["M"], s["N"], s["K"]) == (2401, 2401, 2408), s   # K = 49 * 49 rounded up to 64 bytes
+    assert (s["layout_a"], s["layout_b"], s["transposes"]) == ("k_vec", "k_vec", "fused"), s
+    assert sub.spans()[2] == odd.spans()[2]   # C is the caller's
+    assert odd.gemm_plan().summary() == s      # built once, handed out again
+    # a batch mode as the unit-stride mode of all three: explicit transposes, GEMM on packed operands
+    ttgt = ctc_amd.Plan("akz,kbz->abz", dict(a=64, b=64, k=64, z=8), "f64")
+    assert ttgt.summary()["transposes"] == "explicit"
+    packed = ttgt.gemm_plan().summary()
+    assert packed["transposes"] == "fused" and packed["layout_a"] != "scalar", packed

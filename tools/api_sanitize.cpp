@@ -80,13 +80,13 @@ static void one_case(int n)
     std::map<char, int64_t> ext;
     const int style = (int)(rng() % 5);
     for (char ch : a + b)
-        ext[ch] = style == 0 ? pick({1, 2, 3, 5}) : style == 1 ? pick({2, 4, 8, 64}) : style == 2 ? pick({16, 24, 40, 96}) : style == 3 ? pick({3, 7, 9, 33})
+        ext[ch] = style == 0 ? pick({1, 2, 3, 5}) : style == 1 ? pick({2, 4, 8, 64}) : style == 2 ? pick({16, 24, 40, 96, 49, 1025}) : style == 3 ? pick({3, 7, 9, 33})
                                                                                                                                         : pick({2, 6, 14, 22});
     int64_t space = 1;
-    for (auto &kv : ext) space *= kv.second;
+    for (auto &kv : ext) space = space > ((int64_t)1 << 40) ? space : space * kv.second;
     auto numel = [&](const std::string &m) {
         int64_t v = 1;
-        for (char ch : m) v *= ext[ch];
+        for (char ch : m) v = v > ((int64_t)1 << 40) ? v : v * ext[ch];
         return v;
     };
     if (space > (int64_t)1 << 34 || numel(a) > 1 << 22 || numel(b) > 1 << 22 || numel(c) > 1 << 22) return;  // the offset tables are per row / column
@@ -117,6 +117,12 @@ static void one_case(int n)
     EXPECT(rc == CTC_TC_OK && p != nullptr, "%s: %d %s", what.c_str(), rc, ctc_tc_last_error());
     if (rc != CTC_TC_OK) return;
     queries(p, what);
+    {   // the plan whose GEMM an execution launches: the plan itself or a sub-plan it owns
+        ctc_tc_plan *g = ctc_tc_plan_gemm_plan(p);
+        EXPECT(g != nullptr, "%s: gemm plan: %s", what.c_str(), ctc_tc_last_error());
+        if (g && g != p) queries(g, what + " gemm plan");
+        EXPECT(ctc_tc_plan_gemm_plan(p) == g, "%s: gemm plan handed out twice", what.c_str());
+    }
     // every mode, a few rank counts: evenly divisible or an error, never a crash
     for (char mode : mode_names) {
         const int nr = pick({1, 2, 3, 4, 8});
@@ -217,6 +223,7 @@ static void bad_arguments()
         if (ctc_tc_plan_create(spec.c_str(), (int)many.size(), many.c_str(), e.data(), nullptr, nullptr, nullptr, 0, &p) == CTC_TC_OK) ctc_tc_plan_destroy(p);
     }
     EXPECT(ctc_tc_plan_get(nullptr, 0, nullptr, 0) < 0, "get on a null plan");
+    EXPECT(ctc_tc_plan_gemm_plan(nullptr) == nullptr, "gemm plan of a null plan");
     EXPECT(ctc_tc_plan_destroy(nullptr) == CTC_TC_OK || true, "destroy null");
     (void)ctc_tc_plan_describe(nullptr, nullptr, 0);
     EXPECT(ctc_tc_ttgt_workspace_bytes(nullptr) <= 0, "ttgt workspace of a null plan");
