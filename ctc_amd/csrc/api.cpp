@@ -353,7 +353,14 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     // 16-byte stores of C need an aligned base as well
     g.c_vec = (p.vec_c > 1 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) ? p.vec_c : 1;
     // a result larger than the 256 MiB Infinity Cache cannot stay resident for a consumer anyway
-    g.c_stream = (double)p.M * (double)p.N * (double)p.batch * (double)ctc::dtype_size(p.dtype) > 256.0 * 1048576.0;
+    // ... and the hint pays only when the tiles' stores cover whole 64-byte sectors (free extents 42 / 44 / 46 under
+    // the config-4 contraction: 25 - 30 TFLOP/s with the hint, 33 - 35 without; 40 / 48: 41 / 49 with, 38 without)
+    g.c_stream = (double)p.M * (double)p.N * (double)p.batch * (double)ctc::dtype_size(p.dtype) > 256.0 * 1048576.0 &&
+                 p.c_sectors_whole && (reinterpret_cast<uintptr_t>(C) & 63) == 0;
+    {
+        static const int force = getenv("CTC_TC_C_STREAM") ? atoi(getenv("CTC_TC_C_STREAM")) : -1;  // A/B runs
+        if (force >= 0) g.c_stream = force;
+    }
 
     // vector loads need 16-byte aligned bases; otherwise fall back to element loads
     int la = p.layout_a, lb = p.layout_b;
@@ -375,7 +382,9 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
             // fp64 without the LDS-DMA form (a K that is no multiple of its K-tile, k offsets with more than one
             // stride): the register-staged persistent form is slower than the one-tile-per-workgroup kernels
             // (K = 40 under 31,250 tiles: 19.8 against 36.6 TFLOP/s), so only a forced mode takes it
-            if (dma || p.dtype != ctc::kF64 || force) {
+            // the fp64 LDS-DMA form stores with the streaming hint unconditionally: not for a C whose runs end
+            // inside 64-byte sectors
+            if ((dma && (g.c_stream || force)) || p.dtype != ctc::kF64 || (force && !dma)) {
                 hipError_t es = dma ? ctc::launch_gemm_stream_f64_dma(la, lb, g, stream)
                                     : ctc::launch_gemm_stream(p.dtype, la, lb, g, stream);
                 if (es != hipSuccess) return fail_hip(es, "persistent contraction kernel launch");

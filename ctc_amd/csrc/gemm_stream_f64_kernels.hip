@@ -405,7 +405,11 @@ __global__ void __launch_bounds__(256, Geom<BK>::kTwoPerCu ? 2 : 1) gemm_stream_
 #endif
         double v = acc[SET][i][j][r];
         if (SCALE) v *= alpha;
+#ifdef CTC_SX_PLAIN_STORES  // diagnostic build: without the streaming hint
+        if (ok) *dst = v;
+#else
         if (ok) __builtin_nontemporal_store(v, dst);
+#endif
     };
 
 #ifdef CTC_SX_STAMPS  // diagnostic build: shader-clock ticks per K-tile kind, split at the wait + barrier
@@ -571,8 +575,13 @@ __global__ void __launch_bounds__(256, Geom<BK>::kTwoPerCu ? 2 : 1) gemm_stream_
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int col = wn0 + 16 * j + frow;
-                    if (row < m_lim_prev && col < n_lim_prev)
+                    if (row < m_lim_prev && col < n_lim_prev) {
+#ifdef CTC_SX_PLAIN_STORES
+                        C[ro + slot[BM + col]] = SCALE ? acc[SET][i][j][r] * alpha : acc[SET][i][j][r];
+#else
                         __builtin_nontemporal_store(SCALE ? acc[SET][i][j][r] * alpha : acc[SET][i][j][r], C + ro + slot[BM + col]);
+#endif
+                    }
                 }
             }
     };

@@ -340,6 +340,13 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
     if (c_unit >= 0 && !p.ex_n.empty() && c_unit == p.ex_n[0] && vector_width(p, p.c_modes, sc, c_unit, vmax) == vmax)
         p.vec_c = vmax;
 
+    {
+        const int64_t per64 = 64 / dtype_size(dtype);
+        p.c_sectors_whole = p.vec_c > 1 && p.modes[c_unit].extent % per64 == 0;
+        for (int id : p.c_modes)
+            if (id != c_unit && p.modes[id].extent > 1 && sc[id] % per64 != 0) p.c_sectors_whole = false;
+    }
+
     build_table(p, p.ex_m, ga, p.M, p.row_a);
     build_table(p, p.ex_k, ga, p.K, p.k_a);
     build_table(p, p.ex_k, gb, p.K, p.k_b);

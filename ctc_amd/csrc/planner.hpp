@@ -56,6 +56,11 @@ struct Plan {
     int layout_a = kLayoutScalar, layout_b = kLayoutScalar;
     int vec_a = 1, vec_b = 1;
     int vec_c = 1;  // elements per 16-byte store of C along its unit-stride N mode (1: element stores)
+    // every contiguous run of C a tile stores begins and ends on a 64-byte boundary when C's base does: the
+    // unit-stride N mode's extent and every other stride of C are multiples of 64 bytes.  Only then do stores
+    // with the streaming (non-temporal) hint pay: pieces of a 64-byte sector that arrive from different
+    // workgroups are merged by the L2, which the hint bypasses.
+    bool c_sectors_whole = false;
     Tile tile;
     std::vector<int64_t> row_a, k_a, k_b, col_b, row_c, col_c, bat_a, bat_b, bat_c;
     // k_a[k] == k * ka_stride for every k (the contracted modes fuse into one stride); 0 when they do not

@@ -138,6 +138,27 @@ def test_automatic_routing_of_short_k(cuda):
     assert delta(run("ak,kb->ab", dict(a=8192, b=8192, k=64), "f32")) == (0, 1, 0)
 
 
+def test_streaming_store_hint_needs_whole_sectors(cuda):
+    """abcijk = adij,bcdk with free extents 42 (runs of C of 336 bytes: they end inside 64-byte sectors): stores with
+    the streaming hint run at half the rate there, so the automatic choice leaves the persistent fp64 kernel (which
+    always streams) for the one-tile-per-workgroup kernel; with extents 40 (320-byte runs) it takes the persistent one."""
+    names = ("launches_classic", "launches_dma_gemm", "launches_stream", "launches_stream_f64_dma")
+    for n, want in ((42, (1, 0, 0)), (40, (0, 0, 1))):
+        ext = dict(a=1, b=n, c=n, i=n, j=n, k=n, d=64)
+        plan = ctc_amd.Plan("adij,bcdk->abcijk", ext, "f64")
+        A = torch.zeros(64 * n * n, dtype=torch.float64, device=cuda)
+        B = torch.zeros(n * n * 64 * n, dtype=torch.float64, device=cuda)
+        C = torch.empty(n ** 5, dtype=torch.float64, device=cuda)
+        before = [ctc_amd.get_option(x) for x in names]
+        plan.execute(A, B, C)
+        torch.cuda.synchronize()
+        d = [ctc_amd.get_option(x) - b for x, b in zip(names, before)]
+        assert (d[0] + d[1], d[2], d[3]) == want, (n, d)
+        assert float(C.abs().max()) == 0.0
+        del A, B, C
+        torch.cuda.empty_cache()
+
+
 def _run_case(cuda, oracle, spec, ext, dtype, alpha=1.25):
     A, B, n_out, dA, dB = _operands(oracle, spec, ext, dtype, cuda)
     dC = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
