@@ -433,6 +433,8 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
         // 4 / 12 / 28 %: hence the larger size)
         const bool bf16_short_groups = dtype == kBF16 && !p.k32_affine && !p.k16_affine && p.M >= 4096 && p.N >= 4096 &&
                                        p.K >= 4096 && getenv("CTC_TC_NO_PAD_BF16_GROUPS") == nullptr;
+        // (fp64 operands with vectors but ragged K-tiles - extents 66, 70, 74 ... - gain -1 ... +4 % with the copies:
+        // they keep the fused kernel)
         p.pad_transposes = !off && !p.prefer_transposes && (p.layout_a == kLayoutScalar || p.layout_b == kLayoutScalar || bf16_short_groups) &&
                            p.tile.bm >= 128 && p.M >= min_mn && p.N >= min_mn && p.K >= min_k &&
                            packed(p.a_modes, p.strides_a) && packed(p.b_modes, p.strides_b);
