@@ -124,6 +124,7 @@ struct SkinnyParams {
     int64_t X = 1, Y = 1, O = 1;
     int M = 1, K = 1, batch = 1;
     int transpose = 0;
+    int stream_hint = 0;  // 1: the large operand and C exceed the Infinity Cache and C's runs cover whole 64-byte sectors
     double alpha = 1.0, beta = 0.0;
 };
 hipError_t launch_skinny(int dtype, const SkinnyParams &p, hipStream_t stream);

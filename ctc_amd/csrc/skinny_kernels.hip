@@ -83,7 +83,9 @@ __global__ void __launch_bounds__(kThreads, 4) skinny_same_kernel(const SkinnyPa
     }
 }
 
-template <typename T, int MMAX>
+// NT: loads of the large operand and stores of C carry the streaming hint (operands that do not fit the 256 MiB
+// Infinity Cache: 4.19 -> 4.62 TB/s on 2 x 2 GiB, 4.25 -> 4.53 on 2 x 512 MiB; 3 % slower on 2 x 64 MiB)
+template <typename T, int MMAX, bool NT>
 __global__ void __launch_bounds__(kThreads) skinny_transpose_kernel(const SkinnyParams p, int ntx, int nty)
 {
     typedef typename VecT<T>::type vec_t;
@@ -142,7 +144,10 @@ __global__ void __launch_bounds__(kThreads) skinny_transpose_kernel(const Skinny
         const T *src = bsrc + p.k_b[k];
         vec_t b[V];
 #pragma unroll
-        for (int r = 0; r < V; ++r) b[r] = ly_ok[r] ? *reinterpret_cast<const vec_t *>(src + by[r]) : vec_t(0);
+        for (int r = 0; r < V; ++r) {
+            if (NT) b[r] = ly_ok[r] ? __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(src + by[r])) : vec_t(0);
+            else b[r] = ly_ok[r] ? *reinterpret_cast<const vec_t *>(src + by[r]) : vec_t(0);
+        }
 #pragma unroll
         for (int m = 0; m < MMAX; ++m) {
             if (m < p.M) {
@@ -175,7 +180,8 @@ __global__ void __launch_bounds__(kThreads) skinny_transpose_kernel(const Skinny
                 if (sx_ok[r]) {
                     vec_t *dst = reinterpret_cast<vec_t *>(dst_m + cx[r]);
                     if (beta != (T)0) v += beta * *dst;
-                    *dst = v;
+                    if (NT) __builtin_nontemporal_store(v, dst);
+                    else *dst = v;
                 }
             }
         }
@@ -190,8 +196,12 @@ template <typename T, int MMAX> hipError_t launch_t(const SkinnyParams &p, hipSt
         const int64_t ntx = (p.X + TT - 1) / TT, nty = (p.Y + TT - 1) / TT;
         const int64_t blocks = ntx * nty * p.O;
         if (blocks <= 0 || blocks > 0x7FFFFFFF || p.batch > 65535) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((skinny_transpose_kernel<T, MMAX>), dim3((unsigned)blocks, (unsigned)p.batch), dim3(kThreads), 0,
-                           stream, p, (int)ntx, (int)nty);
+        if (p.stream_hint)
+            hipLaunchKernelGGL((skinny_transpose_kernel<T, MMAX, true>), dim3((unsigned)blocks, (unsigned)p.batch), dim3(kThreads), 0,
+                               stream, p, (int)ntx, (int)nty);
+        else
+            hipLaunchKernelGGL((skinny_transpose_kernel<T, MMAX, false>), dim3((unsigned)blocks, (unsigned)p.batch), dim3(kThreads), 0,
+                               stream, p, (int)ntx, (int)nty);
     } else {
         int64_t blocks = (p.X / V + kThreads - 1) / kThreads;
         if (blocks > 256 * 32) blocks = 256 * 32;
