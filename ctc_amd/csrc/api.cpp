@@ -331,13 +331,13 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
             s.transpose = 1;
             s.bx = t.sk[0]; s.cx = t.sk[1]; s.by = t.sk[2]; s.cy = t.sk[3]; s.bo = t.sk[4]; s.co = t.sk[5];
             s.X = p.sk_X; s.Y = p.sk_Y; s.O = p.sk_O;
-            s.stream_hint = p.c_sectors_whole && (reinterpret_cast<uintptr_t>(C) & 63) == 0 &&
-                            (double)p.N * (double)nb * (double)(p.K + p.M) * (double)ctc::dtype_size(p.dtype) > 256.0 * 1048576.0;
         } else {
             s.transpose = 0;
             s.bx = t.col_b; s.cx = t.col_c;
             s.X = p.N;
         }
+        s.stream_hint = p.c_sectors_whole && (reinterpret_cast<uintptr_t>(C) & 63) == 0 &&
+                        (double)p.N * (double)nb * (double)(p.K + p.M) * (double)ctc::dtype_size(p.dtype) > 256.0 * 1048576.0;
         hipError_t e = ctc::launch_skinny(p.dtype, s, stream);
         if (e != hipSuccess) return fail_hip(e, "skinny contraction kernel launch");
         continue;

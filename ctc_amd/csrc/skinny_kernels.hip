@@ -43,7 +43,8 @@ __device__ __forceinline__ void load_small_operand(T *sA, const SkinnyParams &p,
 
 // (at least four workgroups per CU: without the bound the MMAX = 8 instantiations are compiled to 256
 // registers, one wave per SIMD, and stream at 0.6 - 1.1 TB/s where MMAX = 4 and 16 reach 3 - 4)
-template <typename T, int MMAX>
+// NT: streaming hint on the loads of the large operand and the stores of C (SkinnyParams::stream_hint)
+template <typename T, int MMAX, bool NT>
 __global__ void __launch_bounds__(kThreads, 4) skinny_same_kernel(const SkinnyParams p)
 {
     typedef typename VecT<T>::type vec_t;
@@ -64,12 +65,30 @@ __global__ void __launch_bounds__(kThreads, 4) skinny_same_kernel(const SkinnyPa
         vec_t acc[MMAX];
 #pragma unroll
         for (int m = 0; m < MMAX; ++m) acc[m] = vec_t(0);
-#pragma unroll 4
-        for (int k = 0; k < p.K; ++k) {
-            const vec_t b = *reinterpret_cast<const vec_t *>(bsrc + p.k_b[k]);
+        if (NT) {
+            // operands beyond the Infinity Cache: eight rows of the large operand requested before the first is
+            // used (16 M columns of fp32: 3.75 -> 4.3 TB/s with the hint; cache-resident sizes lose 6 % this way)
+            for (int k0 = 0; k0 < p.K; k0 += 8) {
+                vec_t b[8];
 #pragma unroll
-            for (int m = 0; m < MMAX; ++m)
-                if (m < p.M) acc[m] += sA[m * p.K + k] * b;
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + u < p.K) b[u] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(bsrc + p.k_b[k0 + u]));
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k0 + u < p.K) {
+#pragma unroll
+                        for (int m = 0; m < MMAX; ++m)
+                            if (m < p.M) acc[m] += sA[m * p.K + k0 + u] * b[u];
+                    }
+            }
+        } else {
+#pragma unroll 4
+            for (int k = 0; k < p.K; ++k) {
+                const vec_t b = *reinterpret_cast<const vec_t *>(bsrc + p.k_b[k]);
+#pragma unroll
+                for (int m = 0; m < MMAX; ++m)
+                    if (m < p.M) acc[m] += sA[m * p.K + k] * b;
+            }
         }
 #pragma unroll
         for (int m = 0; m < MMAX; ++m) {
@@ -77,7 +96,8 @@ __global__ void __launch_bounds__(kThreads, 4) skinny_same_kernel(const SkinnyPa
                 vec_t *dst = reinterpret_cast<vec_t *>(cdst + p.row_c[m]);
                 vec_t v = alpha * acc[m];
                 if (beta != (T)0) v += beta * *dst;
-                *dst = v;
+                if (NT) __builtin_nontemporal_store(v, dst);
+                else *dst = v;
             }
         }
     }
@@ -206,7 +226,10 @@ template <typename T, int MMAX> hipError_t launch_t(const SkinnyParams &p, hipSt
         int64_t blocks = (p.X / V + kThreads - 1) / kThreads;
         if (blocks > 256 * 32) blocks = 256 * 32;
         if (blocks <= 0 || p.batch > 65535) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((skinny_same_kernel<T, MMAX>), dim3((unsigned)blocks, (unsigned)p.batch), dim3(kThreads), 0, stream, p);
+        if (p.stream_hint)
+            hipLaunchKernelGGL((skinny_same_kernel<T, MMAX, true>), dim3((unsigned)blocks, (unsigned)p.batch), dim3(kThreads), 0, stream, p);
+        else
+            hipLaunchKernelGGL((skinny_same_kernel<T, MMAX, false>), dim3((unsigned)blocks, (unsigned)p.batch), dim3(kThreads), 0, stream, p);
     }
     return hipGetLastError();
 }

@@ -39,3 +39,17 @@ for c in (128, 1024, 4096):
     ms = timed(lambda: plan.execute(A, B, C))
     nbytes = (A.numel() + C.numel()) * 4
     print(json.dumps({"c": c, "kernel": plan.summary()["kernel"], "ms": round(ms, 4), "TBps": round(nbytes / ms * 1e-9, 2), "GB": round(nbytes * 1e-9, 2)}), flush=True)
+
+# B and C contiguous along the same N mode: ab = ak,kb with a = k = 8
+for n in (1 << 21, (1 << 21) + 4160, 1 << 24, (1 << 24) + 4160, 1 << 26, (1 << 26) + 4160):  # powers of two and not: row pitch against the channel interleave
+    A = torch.empty(64, dtype=torch.float32, device=dev)
+    B = torch.empty(8 * n, dtype=torch.float32, device=dev)
+    C = torch.empty(8 * n, dtype=torch.float32, device=dev)
+    ctc_amd.fill(A, 1)
+    ctc_amd.fill(B, 2)
+    plan = ctc_amd.Plan("ak,kb->ab", dict(a=8, k=8, b=n), "f32")
+    ms = timed(lambda: plan.execute(A, B, C))
+    nbytes = (B.numel() + C.numel()) * 4
+    print(json.dumps({"n": n, "kernel": plan.summary()["kernel"], "ms": round(ms, 4), "TBps": round(nbytes / ms * 1e-9, 2), "GB": round(nbytes * 1e-9, 2)}), flush=True)
+    del A, B, C
+    torch.cuda.empty_cache()
