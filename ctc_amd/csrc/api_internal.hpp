@@ -24,6 +24,8 @@ struct DeviceTables {
     const int64_t *row_a = nullptr, *k_a = nullptr, *k_b = nullptr, *col_b = nullptr;
     const int64_t *row_c = nullptr, *col_c = nullptr, *bat_a = nullptr, *bat_b = nullptr, *bat_c = nullptr;
     const int64_t *sk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // bx cx by cy bo co
+    // a batch of small row-major products (see small_batched in api.cpp): one descriptor per batch entry
+    ctc::SmallGemm *small = nullptr;
     // workspace of this plan on this device (split-K partial sums, or the three packed tensors of the
     // explicit-transpose path): grows on demand; executions on different streams are ordered through
     // ws_done so that they never share it concurrently

@@ -155,6 +155,8 @@ const char *ctc_tc_last_error(void);
  *                   equal shares (stream-K); 1: never shares; 2: shares whenever the launch allows;
  *   "stream_k_group" consecutive tiles whose shares walk K together (1 .. 64); 0 (default): 16, or 8 where that
  *                   leaves less padding;
+ *   "small_batched" 1 (default): a batch of at least 512 row-major products with M, N <= 32 and K <= 64 (fp32: not
+ *                   32 x 32 under a K above 16) runs on the grouped kernel, one wave per product; 0: on the tiled kernels;
  *   "pad_transposes" 1 (default): a plan whose CTC_TC_Q_TILE reports transposes = 2 runs through the padded copies;
  *                   0: it runs the fused kernel with element loads (A/B runs).
  * No reference counterpart.
@@ -164,7 +166,7 @@ int ctc_tc_set_option(const char *name, int64_t value);
  * "launches_classic" (register-staged), "launches_dma_gemm", "launches_stream" (persistent,
  * register-staged), "launches_stream_f64_dma", "launches_bf16_ring" (the bf16 256-tile ring kernel, a
  * subset of "launches_classic"), "padded_executions" (executions that went through the padded copies; their GEMM
- * counts in the launch counters as well).
+ * counts in the launch counters as well), "launches_grouped" (batched plans that took the grouped kernel).
  * Negative ctc_tc_status for an unknown name. */
 int64_t ctc_tc_get_option(const char *name);
 
