@@ -327,16 +327,22 @@ void shape_from_plan(const ctc::Plan &p, int nbatch, ctc::GemmParams &g)
 size_t worst_splitk_bytes(const ctc::Plan &p)
 {
     if (p.kernel != ctc::kKernelGemm) return 0;
-    ctc::GemmParams g;
-    shape_from_plan(p, (int)(p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch), g);
     size_t worst = 0;
-    for (int va = 0; va < 2; ++va)
-        for (int vb = 0; vb < 2; ++vb) {
-            const int la = va ? ctc::kLayoutScalar : p.layout_a, lb = vb ? ctc::kLayoutScalar : p.layout_b;
-            ctc::GemmSchedule sch;
-            if (ctc::schedule_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, &sch) == hipSuccess && sch.ws_bytes > worst)
-                worst = sch.ws_bytes;
-        }
+    // a batch of more entries than one launch takes: whole launches and the rest (the tiles of a batched launch
+    // are scheduled as one list, so the two differ)
+    const int64_t whole = p.batch < kMaxBatchPerLaunch ? p.batch : kMaxBatchPerLaunch, rest = p.batch % whole;
+    for (int64_t nb : {whole, rest}) {
+        if (nb < 1) continue;
+        ctc::GemmParams g;
+        shape_from_plan(p, (int)nb, g);
+        for (int va = 0; va < 2; ++va)
+            for (int vb = 0; vb < 2; ++vb) {
+                const int la = va ? ctc::kLayoutScalar : p.layout_a, lb = vb ? ctc::kLayoutScalar : p.layout_b;
+                ctc::GemmSchedule sch;
+                if (ctc::schedule_gemm(p.dtype, la, lb, p.tile.bm, p.tile.bn, g, &sch) == hipSuccess && sch.ws_bytes > worst)
+                    worst = sch.ws_bytes;
+            }
+    }
     return worst;
 }
 
@@ -862,7 +868,7 @@ int64_t ctc_tc_plan_get(const ctc_tc_plan *plan, int query, int64_t *out, int64_
         if (e != hipSuccess) return fail_hip(e, "contraction schedule");
         v = {sch.nbm, sch.nbn, sch.dp_tiles, sch.tail_tiles, sch.split, (int64_t)sch.ws_bytes,
              (int64_t)ctc::dma_gemm_kind(p.dtype, p.layout_a, p.layout_b, p.tile.bm, p.tile.bn, g),
-             (int64_t)worst_splitk_bytes(p), sch.sk_units};
+             (int64_t)worst_splitk_bytes(p), sch.sk_units, sch.flat_batch};
         break;
     }
     case CTC_TC_Q_SPANS: {

@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     // either the K chunks of the remaining tiles (p.split of equal length per tile) or p.sk_units shares of
     // the remaining tiles' K-tile iterations (a share is worked off piece by piece: the rest of a tile,
     // whole tiles, the beginning of a tile).
-    const int tail_tiles = p.nbm * p.nbn - p.dp_tiles;
+    const int tiles_per_entry = p.nbm * p.nbn;
+    const int tail_tiles = tiles_per_entry * (p.flat_batch > 0 ? p.flat_batch : 1) - p.dp_tiles;
     const int n_items = p.dp_tiles + (p.sk_units > 0 ? p.sk_units : (p.split > 1 ? tail_tiles * p.split : 0));
     const int sk_runs = p.sk_units / p.sk_group;  // runs of K-tile iterations, each worked off by sk_group workgroups
     const int64_t sk_total = (int64_t)((tail_tiles + p.sk_group - 1) / p.sk_group) * nk_total;
@@ -272,6 +273,12 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
             if (tile_rel >= tail_tiles) continue;  // the last group of tiles is not full: nothing for this workgroup there
         }
     }
+    // a launch without a batch dimension in its grid: the tile id counts through the batch entries
+    int bz = blockIdx.y;
+    if (p.flat_batch > 0) {
+        bz = sid / tiles_per_entry;
+        sid -= bz * tiles_per_entry;
+    }
     const int width = p.group * p.nbn;
     const int first_m = (sid / width) * p.group;
     const int gsz = min(p.nbm - first_m, p.group);
@@ -279,7 +286,6 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     const int tn = (sid % width) / gsz;
     const int64_t m0 = (int64_t)tm * BM;
     const int64_t n0 = (int64_t)tn * BN;
-    const int bz = blockIdx.y;
 
     const char *A = reinterpret_cast<const char *>(static_cast<const T *>(p.A) + p.bat_a[bz]);
     const char *B = reinterpret_cast<const char *>(static_cast<const T *>(p.B) + p.bat_b[bz]);
@@ -482,7 +488,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
     // (bounded wait: a workgroup gives up after about 100 us), so that the eight workgroups sharing a panel
     // start the next tile together.  p.ka_stride carries the launch's generation number (the kernel does not
     // use it otherwise): the counters only ever grow.
-    if (gridDim.x < (unsigned)n_items && !partial && sid < p.dp_tiles && sk_it >= sk_end) {
+    if (gridDim.x < (unsigned)n_items && !partial && p.flat_batch == 0 && sid < p.dp_tiles && sk_it >= sk_end) {
         if (t == 0) {
             const int round = (bid - (int)gridDim.x) / (int)gridDim.x;
             unsigned *ctr = &g_round_sync[round & 63][blockIdx.x & 7];
@@ -512,7 +518,8 @@ template <typename T> __global__ void __launch_bounds__(256) sk_fixup_kernel(con
     constexpr int BM = kBM, BN = kBN, ROWS = 16, VPR = BN / 2, RPP = 256 / VPR;
     const int tile_rel = blockIdx.x / (BM / ROWS);
     const int rblk = blockIdx.x % (BM / ROWS);
-    const int tail_tiles = p.nbm * p.nbn - p.dp_tiles;
+    const int tiles_per_entry = p.nbm * p.nbn;
+    const int tail_tiles = tiles_per_entry * (p.flat_batch > 0 ? p.flat_batch : 1) - p.dp_tiles;
     const int g = p.sk_group, units = p.sk_units / g;  // runs
     const int64_t W = (int64_t)((tail_tiles + g - 1) / g) * nk, lo = (int64_t)(tile_rel / g) * nk, hi = lo + nk;
     // runs that begin strictly inside the tile's group of tiles: [u0, u1); the tile's slabs are those of workgroup
@@ -523,14 +530,18 @@ template <typename T> __global__ void __launch_bounds__(256) sk_fixup_kernel(con
     int u1 = u0;
     while (u1 < units && sk_unit_start(u1, W, units, nk) < hi) ++u1;
     if (u0 == u1) return;
-    const int sid = p.dp_tiles + tile_rel;
+    int sid = p.dp_tiles + tile_rel, bz = 0;
+    if (p.flat_batch > 0) {
+        bz = sid / tiles_per_entry;
+        sid -= bz * tiles_per_entry;
+    }
     const int width = p.group * p.nbn;
     const int first_m = (sid / width) * p.group;
     const int gsz = min(p.nbm - first_m, p.group);
     const int tm = first_m + (sid % width) % gsz;
     const int tn = (sid % width) / gsz;
     const T *ws = static_cast<const T *>(p.ws);
-    T *C = static_cast<T *>(p.C);
+    T *C = static_cast<T *>(p.C) + p.bat_c[bz];
     const T alpha = (T)p.alpha;
     const int cv = threadIdx.x % VPR;
     const int64_t n = (int64_t)tn * BN + 2 * cv;
@@ -574,17 +585,29 @@ std::atomic<int> g_stream_k{getenv("CTC_TC_STREAMK") ? atoi(getenv("CTC_TC_STREA
 // chunk's share of the fix-up pass; the same 128 as in gemm_kernels.hip.
 constexpr int kMinChunkK = 128;
 
+// A round of w workgroups on `slots` slots, in units of a full round's time.  With at most one workgroup per CU
+// (w <= slots / 2) a workgroup has the CU's matrix pipes to itself and runs about twice as fast: measured, a tail
+// of 64, 128 or 256 tiles behind full rounds costs 0.44 - 0.49 of a round in both element types, one of 320 a
+// whole round (tools/tail_cost_probe.py).  `light_ok`: whether the launch may count on that (see schedule_one).
+inline double round_cost(int64_t w, int slots, bool light_ok) { return (light_ok && 2 * w <= slots) ? 0.5 : 1.0; }
+
+// The tail tiles in f chunks of equal length each: cost of their rounds in K-tile times.
+inline double split_cost(int64_t tail, int f, int slots, int nk, int ovh, bool light_ok)
+{
+    const int64_t chunks = tail * f, full = chunks / slots, rest = chunks % slots;
+    return ((double)full + (rest ? round_cost(rest, slots, light_ok) : 0.0)) * ((double)nk / f + ovh);
+}
+
 // f_cap: largest f allowed
-int best_split(int64_t tail, int slots, int nk, int min_chunk_tiles, int f_cap)
+int best_split(int64_t tail, int slots, int nk, int min_chunk_tiles, int f_cap, bool light_ok)
 {
     int fmax = nk / min_chunk_tiles;
     if (fmax > 1024) fmax = 1024;
     if (fmax > f_cap) fmax = f_cap;
     int best_f = 1;
-    double best = (double)nk;
+    double best = round_cost(tail, slots, light_ok) * (double)nk;
     for (int f = 2; f <= fmax; ++f) {
-        const double rounds = (double)((tail * f + slots - 1) / slots);
-        const double cost = rounds * ((double)nk / f + min_chunk_tiles);
+        const double cost = split_cost(tail, f, slots, nk, min_chunk_tiles, light_ok);
         if (cost < best * 0.98) {
             best = cost;
             best_f = f;
@@ -599,8 +622,15 @@ template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> hipError_t 
     GemmSchedule s;
     s.nbm = (int)((p.M + kBM - 1) / kBM);
     s.nbn = (int)((p.N + kBN - 1) / kBN);
-    const int64_t tiles = (int64_t)s.nbm * s.nbn;
+    int64_t tiles = (int64_t)s.nbm * s.nbn;
     if (tiles > 0x7FFFFFFF) return hipErrorInvalidValue;
+    // a batched launch: one list of tiles over all entries whenever its length fits (CTC_TC_NO_FLAT_BATCH: A/B runs)
+    static const bool no_flat = getenv("CTC_TC_NO_FLAT_BATCH") != nullptr;
+    // (a grid holds fewer than 2^32 threads: 2^24 workgroups of 256)
+    if (p.batch > 1 && !no_flat && tiles * p.batch <= 0x7FFFFF) {
+        s.flat_batch = p.batch;
+        tiles *= p.batch;
+    }
     s.dp_tiles = (int)tiles;
     s.split = 1;
     s.tail_tiles = 0;
@@ -608,11 +638,19 @@ template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> hipError_t 
     static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
     const int slots = resident_slots<T, LA, LB, RB, NSUB, RAGGED>();
     const int nk = RAGGED ? (int)((p.K / p.k_run) * ((p.k_run + BK - 1) / BK)) : (int)(p.K / BK);
-    if (!no_split && slots > 0 && p.batch == 1) {
+    if (!no_split && slots > 0 && (p.batch == 1 || s.flat_batch > 0)) {
         const int tail = (int)(tiles % slots);
         const int64_t rounds = tiles / slots;
         if (tail > 0) {
             const int ovh = kMinChunkK / BK;  // cost of a piece beside its K-tiles, in K-tile times
+            // A last round of at most one workgroup per CU is counted as half a round (round_cost).  Left to the
+            // dispatcher, the late workgroups of an fp64 launch do not reliably land one per CU once tiles are
+            // long (2 x 512 + 256 tiles of K = 4096 run at 63.6 TFLOP/s against 75.0 cut in two, 1 x 512 + 256 of
+            // K = 8192 at 74.1 or 57.9 from run to run; fp32 shows no such spread), so an fp64 launch that leaves
+            // such a round uncut behind full rounds takes the form in which one workgroup per slot walks the
+            // items (launch_one): the last items then belong to the first workgroups of the grid, one per CU
+            // (the same two shapes: 76.1 and 76.2).
+            static const bool light_ok = getenv("CTC_TC_NO_LIGHT_ROUNDS") == nullptr;  // A/B runs
             // (b) stream-K over the last round and the full round before it (so that a share is at least one
             // tile long and no tile is cut more than once): every workgroup ends at the same time whatever the
             // tile count is, at the price of up to two more pieces per workgroup, a slab per share and the
@@ -645,12 +683,15 @@ template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> hipError_t 
                     }
                 }
                 if (best_share < 1e300) cost_sk = (double)(rounds >= 1 ? rounds - 1 : 0) * nk + best_share + 1.5 * ovh;
+                // fp32: shares measure 2 - 5 % behind equal chunks of the same predicted cost (704 tiles of
+                // K = 8192: 142.1 against 146.8 TFLOP/s; 1216 of K = 4096: 143.3 against 144.6)
+                if (sizeof(T) == 4) cost_sk *= 1.04;
             }
             // (a) the tiles of the last round in f chunks of equal length each (tail x f slabs of workspace; (b)
             // never needs more than one slab per workgroup slot)
-            const int f = best_split(tail, slots, nk, ovh, 1024);
-            const double cost_split = f >= 2 ? (double)rounds * nk + (double)(((int64_t)tail * f + slots - 1) / slots) * ((double)nk / f + ovh)
-                                             : (double)(rounds + 1) * nk;
+            const int f = best_split(tail, slots, nk, ovh, 1024, light_ok);
+            const double cost_split = (double)rounds * nk + (f >= 2 ? split_cost(tail, f, slots, nk, ovh, light_ok)
+                                                                    : round_cost(tail, slots, light_ok) * (double)nk);
             if (cost_sk < cost_split * (sk_mode == 1 ? 1e9 : 0.995)) {
                 s.tail_tiles = sk_tiles;
                 s.dp_tiles = (int)tiles - sk_tiles;
@@ -663,6 +704,11 @@ template <typename T, int LA, int LB, int RB, int NSUB, bool RAGGED> hipError_t 
                 s.dp_tiles = (int)tiles - tail;
                 s.split = f;
                 s.ws_bytes = (size_t)tail * f * kBM * kBN * sizeof(T);
+            }
+            // fp64: more items than slots and a last round (of whole tiles or of chunks) of at most one per CU
+            if (sizeof(T) == 8 && s.sk_units == 0) {
+                const int64_t items = (int64_t)s.dp_tiles + (int64_t)s.tail_tiles * s.split, last = items % slots;
+                if (items > slots && last > 0 && 2 * last <= slots) s.walk = 1;
             }
         }
     }
@@ -680,6 +726,7 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     q.split = sch.split;
     q.sk_units = sch.sk_units;
     q.sk_group = sch.sk_group > 0 ? sch.sk_group : 1;
+    q.flat_batch = sch.flat_batch;
     q.ws = ws;
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
@@ -692,9 +739,9 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     static const int persist = getenv("CTC_TC_DMA_PERSIST") ? atoi(getenv("CTC_TC_DMA_PERSIST")) : -1;
     if (persist != 0) {
         const unsigned slots = (unsigned)resident_slots<T, LA, LB, RB, NSUB, RAGGED>();
-        if (slots >= 8 && slots % 8 == 0 && items > slots && (persist == 1 || (sizeof(T) == 8 && items >= 4 * slots))) items = slots;
+        if (slots >= 8 && slots % 8 == 0 && items > slots && (persist == 1 || sch.walk || (sizeof(T) == 8 && items >= 4 * slots))) items = slots;
     }
-    dim3 grid(items, (unsigned)p.batch, 1);
+    dim3 grid(items, sch.flat_batch > 0 ? 1u : (unsigned)p.batch, 1);
 #ifdef CTC_DMA_ROUND_SYNC
     static std::atomic<int64_t> generation{0};
     q.ka_stride = generation.fetch_add(1) + 1;

@@ -332,14 +332,18 @@ __global__ void __launch_bounds__(256) splitk_fixup_kernel(const GemmParams p)
     constexpr int ROWS = 16, VPR = BN / 2, RPP = 256 / VPR;  // vectors per row, rows per pass
     const int tile_rel = blockIdx.x / (BM / ROWS);
     const int rblk = blockIdx.x % (BM / ROWS);
-    const int sid = p.dp_tiles + tile_rel;
+    int sid = p.dp_tiles + tile_rel, bz = 0;
+    if (p.flat_batch > 0) {  // the tile id counts through the batch entries (GemmParams::flat_batch)
+        bz = sid / (p.nbm * p.nbn);
+        sid -= bz * (p.nbm * p.nbn);
+    }
     const int width = p.group * p.nbn;
     const int first_m = (sid / width) * p.group;
     const int gsz = min(p.nbm - first_m, p.group);
     const int tm = first_m + (sid % width) % gsz;
     const int tn = (sid % width) / gsz;
     const T *slab0 = static_cast<const T *>(p.ws) + (int64_t)tile_rel * p.split * (BM * BN);
-    T *C = static_cast<T *>(p.C);
+    T *C = static_cast<T *>(p.C) + p.bat_c[bz];
     const T alpha = (T)p.alpha, beta = (T)p.beta;
     const int cv = threadIdx.x % VPR;
     const int64_t n = (int64_t)tn * BN + 2 * cv;

@@ -39,6 +39,10 @@ struct GemmParams {
     // group of units walk the same K-tile range of their sk_group tiles together, so that they keep sharing
     // operand panels in the L2 as whole tiles of a round do (sk_units is a multiple of it)
     int sk_units = 0, sk_group = 1;
+    // flat_batch > 0 (LDS-DMA kernel only): the launch's grid has no batch dimension; the tiles of its flat_batch
+    // batch entries form ONE list (entry after entry, nbm * nbn tiles each) that dp_tiles, split and sk_units
+    // refer to, so that the last round of a batched launch is balanced like that of a single product
+    int flat_batch = 0;
     void *ws = nullptr;
     int c_vec = 1;  // > 1: C may be stored in 16-byte vectors of that many elements along N
     int c_stream = 0;  // 1: C is larger than the Infinity Cache: store it with the non-temporal hint
@@ -59,6 +63,8 @@ struct GemmSchedule {
     int nbm = 0, nbn = 0;
     int dp_tiles = 0, tail_tiles = 0, split = 1;
     int sk_units = 0, sk_group = 1;  // > 0: the tail_tiles tiles are shared out in equal runs of K-tiles (GemmParams::sk_units, sk_group)
+    int flat_batch = 0;   // GemmParams::flat_batch
+    int walk = 0;         // 1: one workgroup per slot walks the items (the LDS-DMA kernel's launch decides otherwise by size)
     size_t ws_bytes = 0;  // workspace the launch needs (0: none)
 };
 

@@ -125,7 +125,11 @@ void choose_tile(Plan &p)
     constexpr int64_t kBigTileMinBlocks = 384, kAssumedSlots = 512, kBigTileMinChunk = 512;
     const int64_t big_blocks = blocks(128, 128);
     int64_t big_chunks = big_blocks;
-    if (p.batch == 1 && big_blocks > 0 && big_blocks < kBigTileMinBlocks) {
+    // (a batched product's tiles are cut that way only by the kernel that stages by LDS-DMA, which needs vector
+    // layouts: GemmParams::flat_batch)
+    static const bool batched_too = getenv("CTC_TC_NO_BATCHED_CHUNKS") == nullptr;
+    const bool cut = p.batch == 1 || (batched_too && p.layout_a != kLayoutScalar && p.layout_b != kLayoutScalar);
+    if (cut && big_blocks > 0 && big_blocks < kBigTileMinBlocks) {
         const int64_t by_k = p.K / kBigTileMinChunk, by_slots = (2 * kAssumedSlots) / big_blocks;
         const int64_t f = by_k < by_slots ? by_k : by_slots;
         if (f > 1) big_chunks = big_blocks * f;

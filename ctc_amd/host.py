@@ -157,9 +157,10 @@ class Plan:
     def schedule(self):
         """How the current device will run the tiles (needs a GPU): tiles run whole, tiles of the last,
         partly filled round cut along K, chunks per such tile, workspace bytes."""
-        nbm, nbn, whole, tail, split, ws, form, ws_worst, shares = self.get(_lib.Q_SCHEDULE)
+        nbm, nbn, whole, tail, split, ws, form, ws_worst, shares, listed = self.get(_lib.Q_SCHEDULE)
         return {"tile_rows": nbm, "tile_cols": nbn, "whole_tiles": whole, "tail_tiles": tail, "split": split,
-                "workspace_bytes": ws, "dma_form": form, "workspace_bytes_worst": ws_worst, "stream_k_shares": shares}
+                "workspace_bytes": ws, "dma_form": form, "workspace_bytes_worst": ws_worst, "stream_k_shares": shares,
+                "batch_entries_in_one_tile_list": listed}
 
     # DMA forms of the tiled GEMM (CTC_TC_Q_SCHEDULE): bytes of k per image row, images per operand and stage, ragged
     _DMA_FORMS = {1: (64, 1, "false"), 2: (32, 2, "false"), 3: (32, 1, "false"), 4: (64, 1, "true")}

@@ -106,7 +106,12 @@ enum ctc_tc_query {
                                   64-byte rows with ragged K-tiles), largest workspace bytes over the launch and its
                                   fall-backs to element loads for unaligned bases, stream-K shares (0: the cut tiles
                                   are cut into `chunks per such tile` equal chunks; > 0: the K-tile iterations of the
-                                  cut tiles, taken as one sequence, are dealt out in that many equal shares)} */
+                                  cut tiles, taken as one sequence, are dealt out in that many equal shares),
+                                  batch entries whose tiles the launch counts as ONE list (0: the batch is a grid
+                                  dimension and the tile counts above are per entry; > 0: the counts of whole and cut
+                                  tiles run over tile rows x tile columns x that many entries, so a batched launch's
+                                  last round is balanced like a single product's; of the first launch when the batch
+                                  takes several)} */
     ,
     CTC_TC_Q_SPANS = 28        /* {elements of A, of B, of C the plan addresses, counted from the pointer an execution
                                   is given: 1 + the largest element offset (the packed element count for packed

@@ -273,7 +273,7 @@ def test_schedule_query_reports_the_kernel_that_runs(cuda):
     reported bytes say so)."""
     cases = [
         ("aeim,ebmj->abij", dict(a=48, b=48, i=48, j=48, e=48, m=48), 1),   # K-tiles of 64-byte rows
-        ("aeim,ebmj->abij", dict(a=44, b=44, i=44, j=44, e=44, m=44), 2),   # modes of 44: groups of 4, two images
+        ("aef,feb->ab", dict(a=2304, b=2304, e=120, f=12), 2),               # runs of 12: groups of 4, two images
         ("aef,feb->ab", dict(a=2304, b=2304, e=120, f=14), 4),               # runs of 14: ragged K-tiles
         ("ak,kb->ab", dict(a=2304, b=2304, k=2305), 0),                      # odd K: element loads of A, register-staged
     ]
@@ -396,3 +396,59 @@ def test_seeded_random_contractions_on_large_tiles(cuda, oracle):
         scale = np.abs(want).max()
         assert err <= TOL[dtype] * scale, (n, spec, ext, dtype, alpha, beta, plan.summary()["tile"], d, err, scale)
     assert took_dma >= n_cases // 6, took_dma
+
+
+# Batched launches whose tiles are scheduled as one list over all batch entries: the last round is cut along K
+# (equal chunks or stream-K shares) although no single entry has a tail of its own.
+BATCHED_TAIL_CASES = [
+    ("fewer_tiles_than_slots", "zak,zkb->zab", dict(z=3, a=640, b=512, k=4096), "f64"),          # 60 tiles
+    ("one_round_and_a_bit", "zak,zbk->zab", dict(z=5, a=1408, b=1300, k=1024), "f64"),            # 605 tiles
+    ("two_rounds_and_a_bit", "zka,zkb->zab", dict(z=13, a=1000, b=1400, k=1536), "f64"),          # 1144 tiles
+    ("batch_mode_in_the_middle", "azk,kzb->azb", dict(z=3, a=1100, b=900, k=1280), "f64"),
+    ("two_batch_modes", "yzak,yzkb->yzab", dict(y=2, z=3, a=1000, b=1100, k=384), "f64"),
+    ("ragged_k_tiles", "zaef,zfeb->zab", dict(z=4, a=1280, b=1280, e=20, f=14), "f64"),
+    ("f32_one_round_and_a_bit", "zak,zkb->zab", dict(z=5, a=1408, b=1300, k=2048), "f32"),
+    ("f32_fewer_tiles", "zka,zbk->zab", dict(z=6, a=512, b=640, k=4096), "f32"),
+]
+
+
+@pytest.mark.parametrize("name,spec,ext,dtype", BATCHED_TAIL_CASES, ids=[c[3] + "_" + c[0] for c in BATCHED_TAIL_CASES])
+@pytest.mark.parametrize("stream_k", [1, 2])
+def test_batched_launch_balances_its_last_round(cuda, oracle, name, spec, ext, dtype, stream_k):
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, cuda, dtype)
+    C0 = oracle.fill(n_out, 0xC7C0C, CODE[dtype])
+    plan = ctc_amd.Plan(spec, ext, dtype)
+    s = plan.summary()
+    assert s["kernel"] == "mfma_gemm" and s["tile"][:2] == (128, 128) and s["batch_count"] > 1, s
+    ctc_amd.set_option("stream_mode", 1)
+    ctc_amd.set_option("stream_k", stream_k)
+    try:
+        sch = plan.schedule()
+        assert sch["dma_form"] > 0 and sch["batch_entries_in_one_tile_list"] == s["batch_count"], sch
+        tiles = sch["tile_rows"] * sch["tile_cols"] * s["batch_count"]
+        assert sch["whole_tiles"] + sch["tail_tiles"] == tiles, sch
+        assert (sch["tail_tiles"] > 0) == (sch["workspace_bytes"] > 0), sch
+        # the cases whose last round is worth cutting by the scheduler's costs (the others run whole tiles from one
+        # list: a last round of at most one workgroup per CU is cheap, few K-tiles leave nothing to cut)
+        cut = ("fewer_tiles_than_slots", "one_round_and_a_bit", "two_rounds_and_a_bit", "f32_one_round_and_a_bit", "f32_fewer_tiles")
+        if name in cut:
+            assert sch["tail_tiles"] > 0, sch
+            assert stream_k == 2 or (sch["stream_k_shares"] == 0 and sch["split"] >= 2), sch
+        if stream_k == 2 and name in cut + ("batch_mode_in_the_middle",):
+            assert sch["stream_k_shares"] >= 2, sch  # forced wherever a tile has 64 K-tiles or more
+        dC = torch.from_numpy(C0.copy()).to(cuda)
+        took = _delta(lambda: plan.execute(dA, dB, dC, alpha=0.75, beta=-1.5))
+        assert took == (0, 1, 0, 0), took
+        want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=0.75, beta=-1.5, dtype=CODE[dtype])
+        _check(dC.cpu().numpy(), want, dtype)
+        dC1 = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+        dC2 = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+        plan.execute(dA, dB, dC1)
+        plan.execute(dA, dB, dC2)
+        torch.cuda.synchronize()
+        assert not bool(torch.isnan(dC1).any())
+        assert torch.equal(dC1, dC2)
+        _check(dC1.cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE[dtype]), dtype)
+    finally:
+        ctc_amd.set_option("stream_k", 0)
+        ctc_amd.set_option("stream_mode", 0)
