@@ -418,29 +418,92 @@ template <typename Tag, typename K> int resident_slots(K kernel, int threads)
 }
 template <typename T, int LA, int LB, int BM, int BN> struct KernelTag {};
 
-// Splits the tiles of the last, partly filled round along K.  tiles = q * slots + tail: the q full
-// rounds stay data-parallel; each tail tile is cut into f chunks, which then take
-// ceil(tail * f / slots) rounds of (nk / f + overhead) K-tile times, where the overhead of a chunk
-// (prologue, raw accumulators to the workspace, its share of the fix-up pass) is put at
-// kMinChunkTiles K-tiles.  f minimises that; f = 1 means no split.  Without the overhead term long
-// splits look free: 2304^3 cut 11 ways ran no faster than uncut (45 TFLOP/s), cut 3 ways it runs at 60.
+inline int device_cus()
+{
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cache[dev].load() == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cache[dev].store(cus > 0 ? cus : -1);
+    }
+    const int cus = cache[dev].load();
+    return cus > 0 ? cus : 0;
+}
+
+// Splits tiles along K.  The unit of balance is the CU, not the workgroup slot: the kernels are bound by a CU's
+// matrix pipes, so a launch takes (fixed part) + (workgroups on the busiest CU + d) x (a workgroup's K-tiles),
+// whether those workgroups are resident together or one after another - measured, the time of an uncut launch
+// steps up every 256 tiles (64 x 64 tile, fp64, K = 4096: 0.193 / 0.298 / 0.422 / 0.547 ms for up to
+// 256 / 512 / 768 / 1024 tiles) although 1024 of its workgroups are resident at once (tools/tail_cost_probe.py).
+// d: while a CU holds a single workgroup of the small tile, that workgroup is latency-bound and runs at about two
+// thirds of the CU's rate (the first step above is 1.5 - 1.85 times the later ones); it stays with the longest
+// items of a launch.  The large tile shows no such term.
+// Three schedules, costs in K-tile times (nk per whole tile, nk / f + overhead per chunk, where the overhead -
+// prologue, raw accumulators to the workspace, the chunk's share of the fix-up pass - is `ovh` K-tiles, and a cut
+// at all - the second launch - `pen` more), tiles = w * cus + tail:
+//   whole tiles only:                  (ceil(tiles / cus) + d) * nk
+//   the tail cut into f chunks each:   (w + d) * nk + ceil(tail * f / cus) * chunk + pen      (w >= 1, tail > 0)
+//   every tile cut (tiles <= 4 cus):   (ceil(tiles * f / cus) + d) * chunk + pen
+// Without the overhead term long splits look free: 2304^3 cut 11 ways ran no faster than uncut (45 TFLOP/s), cut
+// 3 ways it runs at 60.  (Counting in rounds of slots instead cut 256 tiles of fp32 K = 1024 seven ways: 44.7
+// TFLOP/s against 54.7 uncut; 512 tiles of K = 576 three ways: 49.9 against 66.4.)
 constexpr int kMinChunkTiles = 8;
 
-inline int best_split(int64_t tail, int slots, int nk)
+struct SplitChoice {
+    int f = 1;          // chunks per cut tile (1: nothing is cut)
+    int64_t cut = 0;    // tiles that are cut: the last `cut` ones
+};
+
+inline SplitChoice best_split(int64_t tiles, int cus, int nk, int ovh, int pen, double d)
 {
-    int fmax = nk / kMinChunkTiles;
-    if (fmax > 1024) fmax = 1024;  // one tile with a very long K may use every slot
-    int best_f = 1;
-    double best = (double)nk;  // unsplit: one round of whole tiles, no workspace
+    int fmax = nk / ovh;
+    if (fmax > 1024) fmax = 1024;  // one tile with a very long K may use every CU several times over
+    SplitChoice best;
+    double best_cost = ((double)((tiles + cus - 1) / cus) + d) * (double)nk;
+    const int64_t w = tiles / cus, tail = tiles % cus;
     for (int f = 2; f <= fmax; ++f) {
-        const double rounds = (double)((tail * f + slots - 1) / slots);
-        const double cost = rounds * ((double)nk / f + kMinChunkTiles);
-        if (cost < best * 0.98) {
-            best = cost;
-            best_f = f;
+        const double chunk = (double)nk / f + ovh;
+        if (w >= 1 && tail > 0) {
+            const double cost = ((double)w + d) * nk + (double)((tail * f + cus - 1) / cus) * chunk + pen;
+            if (cost < best_cost * 0.98) {
+                best_cost = cost;
+                best.f = f;
+                best.cut = tail;
+            }
+        }
+        if (tiles <= 4 * (int64_t)cus) {
+            const double cost = ((double)((tiles * f + cus - 1) / cus) + d) * chunk + pen;
+            if (cost < best_cost * 0.98) {
+                best_cost = cost;
+                best.f = f;
+                best.cut = tiles;
+            }
         }
     }
-    return best_f;
+    return best;
+}
+
+// the schedule of before (CTC_TC_SPLIT_BY_SLOTS=1, A/B runs): the last, partly filled round of `slots` workgroups in
+// f chunks per tile, rounds of chunks counted whole
+inline SplitChoice best_split_by_slots(int64_t tiles, int slots, int nk)
+{
+    SplitChoice best;
+    const int64_t tail = tiles % slots;
+    if (tail == 0) return best;
+    int fmax = nk / kMinChunkTiles;
+    if (fmax > 1024) fmax = 1024;
+    double best_cost = (double)nk;
+    for (int f = 2; f <= fmax; ++f) {
+        const double cost = (double)((tail * f + slots - 1) / slots) * ((double)nk / f + kMinChunkTiles);
+        if (cost < best_cost * 0.98) {
+            best_cost = cost;
+            best.f = f;
+            best.cut = tail;
+        }
+    }
+    return best;
 }
 
 template <typename T, int LA, int LB, int BM, int BN>
@@ -460,16 +523,22 @@ hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
     static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
     const int slots = resident_slots<KernelTag<T, LA, LB, BM, BN>>(gemm_kernel<T, LA, LB, BM, BN, BK, WM, WN>, 64 * WM * WN);
     const int nk = (int)((p.K + BK - 1) / BK);
-    if (!no_split && slots > 0 && p.batch == 1) {
-        const int tail = (int)(tiles % slots);
-        if (tail > 0) {
-            const int f = best_split(tail, slots, nk);
-            if (f >= 2) {
-                s.tail_tiles = tail;
-                s.dp_tiles = (int)tiles - tail;
-                s.split = f;
-                s.ws_bytes = (size_t)tail * f * BM * BN * sizeof(T);
-            }
+    // (the small tile's chunks measure cheaper: 4 - 7 K-tiles of overhead fit its cut launches; a second launch
+    // is some 5 us, 10 of its fp64 K-tiles and 20 of its fp32 ones - the fp32 cuts that lose to whole tiles at
+    // K = 400 ... 800 lose by what 30 make up; a quarter of that in K-tiles of the large tile)
+    constexpr int kChunkOverhead = BM <= 64 ? 6 : kMinChunkTiles;
+    constexpr int kCutPenalty = BM <= 64 ? (sizeof(T) == 4 ? 32 : 10) : (sizeof(T) == 4 ? 8 : 3);
+    constexpr double kLoneWorkgroup = BM <= 64 ? (sizeof(T) == 4 ? 0.75 : 0.5) : 0.0;
+    static const bool by_slots = getenv("CTC_TC_SPLIT_BY_SLOTS") != nullptr;
+    const int cus = device_cus();
+    if (!no_split && slots > 0 && cus > 0 && p.batch == 1) {
+        const SplitChoice c = by_slots ? best_split_by_slots(tiles, slots, nk)
+                                       : best_split(tiles, cus, nk, kChunkOverhead, kCutPenalty, kLoneWorkgroup);
+        if (c.f >= 2 && c.cut > 0) {
+            s.tail_tiles = (int)c.cut;
+            s.dp_tiles = (int)(tiles - c.cut);
+            s.split = c.f;
+            s.ws_bytes = (size_t)c.cut * c.f * BM * BN * sizeof(T);
         }
     }
     *out = s;

@@ -284,7 +284,7 @@ def test_schedule_query_reports_the_kernel_that_runs(cuda):
         assert sch["dma_form"] == form, (spec, ext, sch)
         assert sch["workspace_bytes"] > 0 and sch["workspace_bytes_worst"] >= sch["workspace_bytes"], sch
         fits = sch["workspace_bytes"] <= ctc_amd.noalloc_scratch_bytes()
-        assert fits == (form != 0), sch  # the LDS-DMA kernel's schedules fit by construction; this register-staged one does not
+        assert fits or form == 0, sch  # the LDS-DMA kernel's schedules fit by construction; a register-staged one may not
         ins, outm = spec.split("->")
         la, lb = ins.split(",")
         num = lambda t: int(np.prod([ext[c] for c in t]))  # noqa: E731
@@ -293,7 +293,7 @@ def test_schedule_query_reports_the_kernel_that_runs(cuda):
         c = torch.zeros(num(outm), dtype=torch.float64, device=cuda)
         if fits:
             took = _delta(lambda: plan.execute_noalloc(a, b, c))
-            assert took == (0, 1, 0, 0), (spec, took)
+            assert took == ((0, 1, 0, 0) if form else (1, 0, 0, 0)), (spec, took)
         else:
             with pytest.raises(ctc_amd.CtcError, match="needs %d bytes" % sch["workspace_bytes"]):
                 plan.execute_noalloc(a, b, c)

@@ -19,10 +19,11 @@ TDT = {"f64": torch.float64, "f32": torch.float32}
 CODE = {"f64": 0, "f32": 1}
 
 
-def _run_pair(cuda, oracle, n, dtype, check_oracle):
-    ext = dict(a=n, b=n, i=n, j=n, e=n, m=n)
-    A = oracle.fill(n ** 4, 0xC7C0A, CODE[dtype])
-    B = oracle.fill(n ** 4, 0xC7C0B, CODE[dtype])
+def _run_pair(cuda, oracle, n, dtype, check_oracle, k=None):
+    k = k or n
+    ext = dict(a=n, b=n, i=n, j=n, e=k, m=k)
+    A = oracle.fill(n * n * k * k, 0xC7C0A, CODE[dtype])
+    B = oracle.fill(n * n * k * k, 0xC7C0B, CODE[dtype])
     dA, dB = torch.from_numpy(A).to(cuda), torch.from_numpy(B).to(cuda)
     plan = ctc_amd.Plan(SPEC, ext, dtype)
     plan.prepare()
@@ -54,7 +55,7 @@ def _run_pair(cuda, oracle, n, dtype, check_oracle):
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_noalloc_matches_execute_twice_second_smaller(cuda, oracle, dtype):
     _run_pair(cuda, oracle, 48, dtype, check_oracle=False)  # 2304^3: large tile, last round cut along K
-    _run_pair(cuda, oracle, 24, dtype, check_oracle=True)   # 576^3: fewer tiles than slots, all cut along K
+    _run_pair(cuda, oracle, 16, dtype, check_oracle=True, k=48)   # 256^2 x 2304: a few small tiles, all cut along K
 
 
 def test_noalloc_needs_prepare_and_rejects_oversized_schedules(cuda, oracle):
@@ -64,14 +65,14 @@ def test_noalloc_needs_prepare_and_rejects_oversized_schedules(cuda, oracle):
     plan = ctc_amd.Plan(SPEC, ext, "f64")
     with pytest.raises(ctc_amd.CtcError, match="ctc_tc_plan_prepare"):
         plan.execute_noalloc(x, x, x.clone())
-    # 300 tiles of 128 x 128 under a long, odd K (element loads of A: the register-staged kernel, whose tiles
-    # are all cut into equal K chunks, several rounds of them): more partial sums than the fixed buffer holds
+    # 130 tiles of 128 x 128 under a long, odd K (element loads of A: the register-staged kernel, whose tiles
+    # are all cut into equal K chunks, several per CU): more partial sums than the fixed buffer holds
     # must be refused, not truncated
-    big = ctc_amd.Plan("ak,kb->ab", dict(a=2560, b=1920, k=16385), "f64")
+    big = ctc_amd.Plan("ak,kb->ab", dict(a=1280, b=1664, k=16385), "f64")
     big.prepare()
     sch = big.schedule()
     assert sch["dma_form"] == 0 and sch["workspace_bytes"] > ctc_amd.noalloc_scratch_bytes(), sch
-    a = torch.zeros(2560 * 16385, dtype=torch.float64, device=cuda)
+    a = torch.zeros(2560 * 16385, dtype=torch.float64, device=cuda)  # room for both shapes of this test
     c = torch.zeros(2560 * 1920, dtype=torch.float64, device=cuda)
     with pytest.raises(ctc_amd.CtcError, match="scratch"):
         big.execute_noalloc(a, a, c)

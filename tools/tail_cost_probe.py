@@ -38,11 +38,17 @@ if os.environ.get("TAIL_PROBE_HALF"):
     # tails of half the slots (and 3/8) behind one to five full rounds
     GRIDS = ((24, 32), (40, 32), (56, 32), (72, 32), (88, 32), (22, 32), (38, 32), (54, 32))
     KS = (512, 1024, 2048, 4096, 8192)
+EDGE = 128
+if os.environ.get("TAIL_PROBE_SMALL"):
+    # the 64 x 64 tile (run under CTC_TC_FORCE_TILE=64): tile counts from a quarter of a CU each to two rounds
+    EDGE = 64
+    GRIDS = ((8, 8), (8, 16), (12, 16), (16, 16), (16, 20), (16, 24), (16, 32), (20, 32), (24, 32), (28, 32), (32, 32), (32, 36), (32, 40), (32, 48), (32, 64))
+    KS = (576, 1024, 4096)
 for dt in which:
     tdt = torch.float64 if dt == "f64" else torch.float32
     for k in KS:
         for tr, tc in GRIDS:
-            m, n = tr * 128, tc * 128
+            m, n = tr * EDGE, tc * EDGE
             A = torch.empty(m * k, dtype=tdt, device=dev)
             B = torch.empty(k * n, dtype=tdt, device=dev)
             C = torch.empty(m * n, dtype=tdt, device=dev)
@@ -50,12 +56,13 @@ for dt in which:
             ctc_amd.fill(B, 2)
             plan = ctc_amd.Plan("ak,kb->ab", dict(a=m, b=n, k=k), dt)
             plan.prepare()
-            out = {"dtype": dt, "tiles": tr * tc, "full_rounds": tr * tc // 512, "tail": tr * tc % 512, "k": k, "no_splitk_env": os.environ.get("CTC_TC_NO_SPLITK")}
+            out = {"dtype": dt, "tiles": tr * tc, "full_rounds": tr * tc // 512, "tail": tr * tc % 512, "k": k, "tile_edge": EDGE, "no_splitk_env": os.environ.get("CTC_TC_NO_SPLITK")}
             for mode, label in ((0, "by_cost"), (1, "chunks_only"), (2, "shares")):
                 ctc_amd.set_option("stream_k", mode)
                 ctc_amd.set_option("stream_mode", 1)
                 sch = plan.schedule()
                 ms = timed(lambda: plan.execute(A, B, C))
+                out["tile"] = list(plan.summary()["tile"])[:2]
                 out[label] = {"ms": round(ms, 4), "tflops": round(2.0 * m * n * k / ms * 1e-9, 1), "cut": sch["tail_tiles"], "split": sch["split"], "shares": sch["stream_k_shares"]}
                 if os.environ.get("CTC_TC_NO_SPLITK"):
                     break
