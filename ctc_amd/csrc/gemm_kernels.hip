@@ -117,6 +117,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
             partial = true;
         }
     }
+    // a launch without a batch dimension in its grid: the tile id counts through the batch entries (GemmParams::flat_batch)
+    int bz = blockIdx.y;
+    const int list_id = sid;  // position in the launch's list of tiles: what a chunk's workspace slab is counted from
+    if (p.flat_batch > 0) {
+        bz = sid / (p.nbm * p.nbn);
+        sid -= bz * (p.nbm * p.nbn);
+    }
     const int width = p.group * p.nbn;
     const int first_m = (sid / width) * p.group;
     const int gsz = min(p.nbm - first_m, p.group);
@@ -124,7 +131,6 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     const int tn = (sid % width) / gsz;
     const int64_t m0 = (int64_t)tm * BM;
     const int64_t n0 = (int64_t)tn * BN;
-    const int bz = blockIdx.y;
 
     const T *A = static_cast<const T *>(p.A) + p.bat_a[bz];
     const T *B = static_cast<const T *>(p.B) + p.bat_b[bz];
@@ -303,7 +309,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
     CTC_STAMP(st_loop1);
 #endif
 
-    store_tile<T, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, sid, chunk);
+    store_tile<T, BM, BN, TM, TN>(p, acc, s_coff, C, wm0, wn0, lane, partial, list_id, chunk);
 #ifdef CTC_CLOCK
     if (t == 0 && blockIdx.y == 0 && (blockIdx.x == 700 || blockIdx.x == 2500 || blockIdx.x == 4500)) {
         const unsigned long long dc = __builtin_readcyclecounter() - ck_core0, dr = __builtin_amdgcn_s_memrealtime() - ck_real0;
@@ -514,8 +520,15 @@ hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
     GemmSchedule s;
     s.nbm = (int)((p.M + BM - 1) / BM);
     s.nbn = (int)((p.N + BN - 1) / BN);
-    const int64_t tiles = (int64_t)s.nbm * s.nbn;
+    int64_t tiles = (int64_t)s.nbm * s.nbn;
     if (tiles > 0x7FFFFFFF) return hipErrorInvalidValue;
+    // a batched launch: one list of tiles over all entries whenever its length fits a grid (2^24 workgroups of
+    // 256 threads), so that it is cut like a single product (CTC_TC_NO_FLAT_BATCH: A/B runs)
+    static const bool no_flat = getenv("CTC_TC_NO_FLAT_BATCH") != nullptr;
+    if (p.batch > 1 && !no_flat && tiles * p.batch <= 0x7FFFFF) {
+        s.flat_batch = p.batch;
+        tiles *= p.batch;
+    }
     s.dp_tiles = (int)tiles;
     s.split = 1;
     s.tail_tiles = 0;
@@ -531,7 +544,7 @@ hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
     constexpr double kLoneWorkgroup = BM <= 64 ? (sizeof(T) == 4 ? 0.75 : 0.5) : 0.0;
     static const bool by_slots = getenv("CTC_TC_SPLIT_BY_SLOTS") != nullptr;
     const int cus = device_cus();
-    if (!no_split && slots > 0 && cus > 0 && p.batch == 1) {
+    if (!no_split && slots > 0 && cus > 0 && (p.batch == 1 || s.flat_batch > 0)) {
         const SplitChoice c = by_slots ? best_split_by_slots(tiles, slots, nk)
                                        : best_split(tiles, cus, nk, kChunkOverhead, kCutPenalty, kLoneWorkgroup);
         if (c.f >= 2 && c.cut > 0) {
@@ -554,10 +567,11 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     q.nbn = sch.nbn;
     q.dp_tiles = sch.dp_tiles;
     q.split = sch.split;
+    q.flat_batch = sch.flat_batch;
     q.ws = ws;
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
-    dim3 grid((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1);
+    dim3 grid((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), sch.flat_batch > 0 ? 1u : (unsigned)p.batch, 1);
     dim3 block(64 * WM * WN, 1, 1);
     // diagnostic knob: extra dynamic LDS per block lowers the number of co-resident blocks per CU
     static const size_t extra_lds = getenv("CTC_TC_DEBUG_EXTRA_LDS") ? (size_t)atol(getenv("CTC_TC_DEBUG_EXTRA_LDS")) : 0;

@@ -39,7 +39,7 @@ struct GemmParams {
     // group of units walk the same K-tile range of their sk_group tiles together, so that they keep sharing
     // operand panels in the L2 as whole tiles of a round do (sk_units is a multiple of it)
     int sk_units = 0, sk_group = 1;
-    // flat_batch > 0 (LDS-DMA kernel only): the launch's grid has no batch dimension; the tiles of its flat_batch
+    // flat_batch > 0 (fp64 / fp32 tiled kernels): the launch's grid has no batch dimension; the tiles of its flat_batch
     // batch entries form ONE list (entry after entry, nbm * nbn tiles each) that dp_tiles, split and sk_units
     // refer to, so that the last round of a batched launch is balanced like that of a single product
     int flat_batch = 0;

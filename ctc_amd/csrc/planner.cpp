@@ -125,14 +125,24 @@ void choose_tile(Plan &p)
     constexpr int64_t kBigTileMinBlocks = 384, kAssumedSlots = 512, kBigTileMinChunk = 512;
     const int64_t big_blocks = blocks(128, 128);
     int64_t big_chunks = big_blocks;
-    // (a batched product's tiles are cut that way only by the kernel that stages by LDS-DMA, which needs vector
-    // layouts: GemmParams::flat_batch)
+    // (a batched launch's tiles form one list that is cut like a single product's: GemmParams::flat_batch)
     static const bool batched_too = getenv("CTC_TC_NO_BATCHED_CHUNKS") == nullptr;
-    const bool cut = p.batch == 1 || (batched_too && p.layout_a != kLayoutScalar && p.layout_b != kLayoutScalar);
+    const bool cut = p.batch == 1 || batched_too;
     if (cut && big_blocks > 0 && big_blocks < kBigTileMinBlocks) {
         const int64_t by_k = p.K / kBigTileMinChunk, by_slots = (2 * kAssumedSlots) / big_blocks;
         const int64_t f = by_k < by_slots ? by_k : by_slots;
-        if (f > 1) big_chunks = big_blocks * f;
+        // Fewer large tiles than seven eighths of the CUs cannot be cut two or three ways into an even load (192
+        // tiles are 1.5 or 2.25 chunks per CU), and left whole they leave CUs idle: 2048 x 1536 x 1100 runs at 43.9
+        // TFLOP/s on 192 large tiles and at 56.0 on 768 small ones (fp32 71.7 / 91.0), K = 1536 at 52.7 / 58.2;
+        // from 224 tiles on the large tile is ahead (1792 x 2048 x 1280: 60.1 / 55.7).
+        // With element loads on an operand (odd unit-stride extents) the large tile runs on the register-staged
+        // kernel: fp64 then keeps the small tile below 256 large tiles, where the padded K-major copies begin
+        // (1681 x 1763 x 1035: 37.6 against 49.3 TFLOP/s, 1849^3: 45.5 against 52.9); fp32 takes those copies
+        // from 1024 x 1024 on, and they need the large tile (1601 x 1603 x 1537, both operands by elements: 70.4
+        // through the copies against 49.5 on the small tile), so there the count alone decides as before.
+        const bool vectors = p.layout_a != kLayoutScalar && p.layout_b != kLayoutScalar;
+        const int64_t few_blocks = vectors ? 224 : (p.dtype == kF64 ? 256 : 0);
+        if (f > 1 && (big_blocks >= few_blocks || f >= 4)) big_chunks = big_blocks * f;
     }
     if (p.M >= 96 && p.N >= 96 && (big_blocks >= kBigTileMinBlocks || big_chunks >= kBigTileMinBlocks)) {
         t.bm = 128; t.bn = 128;

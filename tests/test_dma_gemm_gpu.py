@@ -404,7 +404,7 @@ BATCHED_TAIL_CASES = [
     ("fewer_tiles_than_slots", "zak,zkb->zab", dict(z=3, a=640, b=512, k=4096), "f64"),          # 60 tiles
     ("one_round_and_a_bit", "zak,zbk->zab", dict(z=5, a=1408, b=1300, k=1024), "f64"),            # 605 tiles
     ("two_rounds_and_a_bit", "zka,zkb->zab", dict(z=13, a=1000, b=1400, k=1536), "f64"),          # 1144 tiles
-    ("batch_mode_in_the_middle", "azk,kzb->azb", dict(z=3, a=1100, b=900, k=1280), "f64"),
+    ("batch_mode_in_the_middle", "azk,kzb->azb", dict(z=3, a=1200, b=900, k=1280), "f64"),
     ("two_batch_modes", "yzak,yzkb->yzab", dict(y=2, z=3, a=1000, b=1100, k=384), "f64"),
     ("ragged_k_tiles", "zaef,zfeb->zab", dict(z=4, a=1280, b=1280, e=20, f=14), "f64"),
     ("f32_one_round_and_a_bit", "zak,zkb->zab", dict(z=5, a=1408, b=1300, k=2048), "f32"),
@@ -452,3 +452,41 @@ def test_batched_launch_balances_its_last_round(cuda, oracle, name, spec, ext, d
     finally:
         ctc_amd.set_option("stream_k", 0)
         ctc_amd.set_option("stream_mode", 0)
+
+
+# The same on the register-staged kernels (the small tile; the large tile under element loads).
+BATCHED_CLASSIC_CASES = [
+    ("small_tile_long_k", "zak,zkb->zab", dict(z=6, a=200, b=180, k=2048), "f64", 64),            # 72 tiles, all cut
+    ("small_tile_two_per_cu", "zak,zbk->zab", dict(z=5, a=640, b=576, k=1024), "f64", 64),        # 450 tiles
+    ("small_tile_f32", "zka,zkb->zab", dict(z=7, a=256, b=192, k=4096), "f32", 64),               # 84 tiles
+    ("large_tile_element_loads", "zak,zkb->zab", dict(z=3, a=1500, b=1400, k=1025), "f64", 128),  # odd K: A by elements
+    ("small_tile_odd_everything", "zak,zkb->zab", dict(z=9, a=131, b=77, k=1501), "f64", 64),
+]
+
+
+@pytest.mark.parametrize("name,spec,ext,dtype,tile", BATCHED_CLASSIC_CASES, ids=[c[3] + "_" + c[0] for c in BATCHED_CLASSIC_CASES])
+def test_batched_launch_on_register_staged_kernels(cuda, oracle, name, spec, ext, dtype, tile):
+    A, B, n_out, dA, dB = _operands(oracle, spec, ext, cuda, dtype)
+    C0 = oracle.fill(n_out, 0xC7C0C, CODE[dtype])
+    plan = ctc_amd.Plan(spec, ext, dtype)
+    s = plan.summary()
+    assert s["kernel"] == "mfma_gemm" and s["tile"][:2] == (tile, tile) and s["batch_count"] > 1, s
+    sch = plan.schedule()
+    assert sch["dma_form"] == 0 and sch["batch_entries_in_one_tile_list"] == s["batch_count"], sch
+    assert sch["whole_tiles"] + sch["tail_tiles"] == sch["tile_rows"] * sch["tile_cols"] * s["batch_count"], sch
+    assert (sch["tail_tiles"] > 0) == (sch["workspace_bytes"] > 0), sch
+    if name in ("small_tile_long_k", "small_tile_f32"):
+        assert sch["tail_tiles"] > 0 and sch["split"] >= 2, sch
+    dC = torch.from_numpy(C0.copy()).to(cuda)
+    took = _delta(lambda: plan.execute(dA, dB, dC, alpha=0.75, beta=-1.5))
+    assert took == (1, 0, 0, 0), took
+    want = oracle.contract(spec, ext, A, B, C=C0.copy(), alpha=0.75, beta=-1.5, dtype=CODE[dtype])
+    _check(dC.cpu().numpy(), want, dtype)
+    dC1 = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+    dC2 = torch.full((n_out,), float("nan"), dtype=TDT[dtype], device=cuda)
+    plan.execute(dA, dB, dC1)
+    plan.execute(dA, dB, dC2)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(dC1).any())
+    assert torch.equal(dC1, dC2)
+    _check(dC1.cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE[dtype]), dtype)

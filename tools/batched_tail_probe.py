@@ -35,6 +35,12 @@ dev = torch.device("cuda:0")
 CASES = ((3, 3000, 3000, 3000), (5, 2000, 2000, 2000), (7, 1500, 1500, 4096), (3, 640, 512, 4096), (10, 1024, 1024, 1024), (12, 1024, 1024, 1024),
          (20, 768, 768, 2048), (6, 512, 640, 8192), (2, 4096, 4096, 1024), (9, 1280, 1152, 512), (33, 512, 512, 512), (3, 1024, 1024, 16384),
          (4, 2048, 2048, 2048), (64, 512, 512, 512), (100, 384, 384, 1024), (17, 896, 896, 896))
+if os.environ.get("BATCHED_SMALL"):
+    # batches of products small enough for the 64 x 64 tile (or close to the boundary between the tiles)
+    CASES = ((8, 300, 300, 300), (16, 256, 256, 4096), (6, 200, 180, 2048), (32, 128, 128, 2048), (5, 640, 576, 1024), (100, 100, 100, 1000),
+             (20, 384, 384, 384), (3, 500, 500, 8000), (2, 1000, 1000, 1000), (12, 192, 192, 16384), (50, 64, 64, 4096), (4, 700, 900, 1100))
+if os.environ.get("PROBE_CASES"):  # "batch,m,n,k;batch,m,n,k;..."
+    CASES = tuple(tuple(int(v) for v in c.split(",")) for c in os.environ["PROBE_CASES"].split(";"))
 for dt, tdt in (("f64", torch.float64), ("f32", torch.float32)):
     for z, m, n, k in CASES:
         A = torch.empty(z * m * k, dtype=tdt, device=dev)
@@ -42,7 +48,7 @@ for dt, tdt in (("f64", torch.float64), ("f32", torch.float32)):
         C = torch.empty(z * m * n, dtype=tdt, device=dev)
         ctc_amd.fill(A, 1)
         ctc_amd.fill(B, 2)
-        plan = ctc_amd.Plan("zak,zkb->zab", dict(z=z, a=m, b=n, k=k), dt)
+        plan = ctc_amd.Plan("zak,zkb->zab", dict(z=z, a=m, b=n, k=k), dt) if z > 1 else ctc_amd.Plan("ak,kb->ab", dict(a=m, b=n, k=k), dt)
         plan.prepare()
         ms = timed(lambda: plan.execute(A, B, C))
         s, sch = plan.summary(), plan.schedule()

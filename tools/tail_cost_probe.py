@@ -44,20 +44,29 @@ if os.environ.get("TAIL_PROBE_SMALL"):
     EDGE = 64
     GRIDS = ((8, 8), (8, 16), (12, 16), (16, 16), (16, 20), (16, 24), (16, 32), (20, 32), (24, 32), (28, 32), (32, 32), (32, 36), (32, 40), (32, 48), (32, 64))
     KS = (576, 1024, 4096)
+if os.environ.get("TAIL_PROBE_BF16"):
+    # the 128 x 128 bf16 tile (the planner takes it below 192 tiles of 256 x 256)
+    GRIDS = ((8, 16), (8, 32), (12, 32), (14, 32), (16, 32), (18, 32), (20, 32), (22, 32))
+    KS = (1024, 4096, 16384)
+    which = ["bf16"]
 for dt in which:
-    tdt = torch.float64 if dt == "f64" else torch.float32
+    tdt = {"f64": torch.float64, "f32": torch.float32, "bf16": torch.bfloat16}[dt]
     for k in KS:
         for tr, tc in GRIDS:
             m, n = tr * EDGE, tc * EDGE
             A = torch.empty(m * k, dtype=tdt, device=dev)
             B = torch.empty(k * n, dtype=tdt, device=dev)
             C = torch.empty(m * n, dtype=tdt, device=dev)
-            ctc_amd.fill(A, 1)
-            ctc_amd.fill(B, 2)
+            if dt == "bf16":
+                A.copy_(torch.rand(m * k, dtype=torch.float32, device=dev) - 0.5)
+                B.copy_(torch.rand(k * n, dtype=torch.float32, device=dev) - 0.5)
+            else:
+                ctc_amd.fill(A, 1)
+                ctc_amd.fill(B, 2)
             plan = ctc_amd.Plan("ak,kb->ab", dict(a=m, b=n, k=k), dt)
             plan.prepare()
             out = {"dtype": dt, "tiles": tr * tc, "full_rounds": tr * tc // 512, "tail": tr * tc % 512, "k": k, "tile_edge": EDGE, "no_splitk_env": os.environ.get("CTC_TC_NO_SPLITK")}
-            for mode, label in ((0, "by_cost"), (1, "chunks_only"), (2, "shares")):
+            for mode, label in ((0, "by_cost"), (1, "chunks_only"), (2, "shares")) if dt != "bf16" else ((0, "by_cost"),):
                 ctc_amd.set_option("stream_k", mode)
                 ctc_amd.set_option("stream_mode", 1)
                 sch = plan.schedule()
