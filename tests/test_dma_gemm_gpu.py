@@ -490,3 +490,54 @@ def test_batched_launch_on_register_staged_kernels(cuda, oracle, name, spec, ext
     assert not bool(torch.isnan(dC1).any())
     assert torch.equal(dC1, dC2)
     _check(dC1.cpu().numpy(), oracle.contract(spec, ext, A, B, dtype=CODE[dtype]), dtype)
+
+
+def _random_batched_cases(count, seed=20250311):
+    rng = np.random.RandomState(seed)
+    specs = ("zak,zkb->zab", "zak,zbk->zab", "zka,zkb->zab", "zka,zbk->zab", "azk,kzb->azb")
+    out = []
+    for i in range(count):
+        dtype = "f32" if i % 3 == 2 else "f64"
+        z = int(rng.randint(2, 13))
+        m, n = int(rng.randint(40, 900)), int(rng.randint(40, 900))
+        k = int(rng.choice([rng.randint(200, 700), rng.randint(1000, 3000), rng.randint(4000, 9000)]))
+        if i % 2 == 0:  # vector layouts: multiples of four everywhere
+            m, n, k = m // 4 * 4, n // 4 * 4, k // 16 * 16
+        out.append((specs[i % len(specs)], dict(z=z, a=m, b=n, k=k), dtype))
+    return out
+
+
+_BATCHED_RANDOM = _random_batched_cases(int(os.environ.get("CTC_BATCH_FUZZ_CASES", "30")), int(os.environ.get("CTC_BATCH_FUZZ_SEED", "20250311"), 0))
+
+
+@pytest.mark.parametrize("spec,ext,dtype", _BATCHED_RANDOM,
+                         ids=["%s_%dx%dx%dx%d_%s" % (c[0].replace(",", "_").replace("->", "_"), c[1]["z"], c[1]["a"], c[1]["b"], c[1]["k"], c[2]) for c in _BATCHED_RANDOM])
+def test_batched_random_shapes_against_single_products(cuda, spec, ext, dtype):
+    """Seeded random batches (2 - 12 entries of 40 - 900 rows and columns under K from 200 to 9000, even and odd
+    sizes): the batched plan - one list of tiles, cut along K where the scheduler says so - against one plan per
+    entry on that entry's slice of the operands.  The two add the same products in different orders."""
+    z, m, n, k = ext["z"], ext["a"], ext["b"], ext["k"]
+    ins, outm = spec.split("->")
+    la, lb = ins.split(",")
+    A = torch.empty(z * m * k, dtype=TDT[dtype], device=cuda)
+    B = torch.empty(z * k * n, dtype=TDT[dtype], device=cuda)
+    ctc_amd.fill(A, 0xC7C0A)
+    ctc_amd.fill(B, 0xC7C0B)
+    C0 = torch.empty(z * m * n, dtype=TDT[dtype], device=cuda)
+    ctc_amd.fill(C0, 0xC7C0C)
+    got = C0.clone()
+    plan = ctc_amd.Plan(spec, ext, dtype)
+    plan.execute(A, B, got, alpha=1.5, beta=0.25)
+    # entry by entry through strided single products
+    shape = lambda letters: [ext[c] for c in letters]  # noqa: E731
+    At, Bt, Wt = A.view(shape(la)), B.view(shape(lb)), C0.clone().view(shape(outm))
+    single = la.replace("z", "") + "," + lb.replace("z", "") + "->" + outm.replace("z", "")
+    sa = lambda t, letters: [t.stride(i) for i, c in enumerate(letters) if c != "z"]  # noqa: E731
+    one = ctc_amd.Plan(single, dict(a=m, b=n, k=k), dtype, sa(At, la), sa(Bt, lb), sa(Wt, outm))
+    for e in range(z):
+        ea, eb, ec = At.select(la.index("z"), e), Bt.select(lb.index("z"), e), Wt.select(outm.index("z"), e)
+        one.execute(A[ea.storage_offset():], B[eb.storage_offset():], Wt.view(-1)[ec.storage_offset():], alpha=1.5, beta=0.25)
+    torch.cuda.synchronize()
+    want = Wt.reshape(-1)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 4 * TOL[dtype] * scale, (plan.summary(), plan.schedule())
