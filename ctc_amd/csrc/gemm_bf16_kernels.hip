@@ -411,13 +411,19 @@ __global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(co
             partial = true;
         }
     }
+    // a launch without a batch dimension in its grid: the tile id counts through the batch entries (GemmParams::flat_batch)
+    const int list_id = sid;  // position in the launch's list of tiles: what a chunk's workspace slab is counted from
+    int bz = blockIdx.y;
+    if (p.flat_batch > 0) {
+        bz = sid / (p.nbm * p.nbn);
+        sid -= bz * (p.nbm * p.nbn);
+    }
     const int width = p.group * p.nbn;
     const int first_m = (sid / width) * p.group;
     const int gsz = min(p.nbm - first_m, p.group);
     const int tm = first_m + (sid % width) % gsz;
     const int tn = (sid % width) / gsz;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    const int bz = blockIdx.y;
 
     const unsigned short *A = static_cast<const unsigned short *>(p.A) + p.bat_a[bz];
     const unsigned short *B = static_cast<const unsigned short *>(p.B) + p.bat_b[bz];
@@ -566,7 +572,7 @@ __global__ void __launch_bounds__(2 * BT, BT == 128 ? 2 : 1) gemm_bf16_kernel(co
         __syncthreads();
     }
 
-    store_tile_bf16<BT, TM, TN>(p, acc, smem, C, m0, n0, wm0, wn0, t, lane, partial, sid, chunk);
+    store_tile_bf16<BT, TM, TN>(p, acc, smem, C, m0, n0, wm0, wn0, t, lane, partial, list_id, chunk);
 }
 
 // ---- ring kernel ---------------------------------------------------------------------------------------
@@ -735,13 +741,19 @@ template <int LA, int LB, int KG> __global__ void __launch_bounds__(512, 1) gemm
             partial = true;
         }
     }
+    // a launch without a batch dimension in its grid: the tile id counts through the batch entries (GemmParams::flat_batch)
+    const int list_id = sid;  // position in the launch's list of tiles: what a chunk's workspace slab is counted from
+    int bz = blockIdx.y;
+    if (p.flat_batch > 0) {
+        bz = sid / (p.nbm * p.nbn);
+        sid -= bz * (p.nbm * p.nbn);
+    }
     const int width = p.group * p.nbn;
     const int first_m = (sid / width) * p.group;
     const int gsz = min(p.nbm - first_m, p.group);
     const int tm = first_m + (sid % width) % gsz;
     const int tn = (sid % width) / gsz;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
-    const int bz = blockIdx.y;
 
     const char *A = reinterpret_cast<const char *>(static_cast<const unsigned short *>(p.A) + p.bat_a[bz]);
     const char *B = reinterpret_cast<const char *>(static_cast<const unsigned short *>(p.B) + p.bat_b[bz]);
@@ -865,7 +877,7 @@ template <int LA, int LB, int KG> __global__ void __launch_bounds__(512, 1) gemm
         printf("[clock] block %d: %llu core ticks in %llu x 10 ns -> %.3f GHz (K loop only)\n", (int)blockIdx.x, dc, dr, (double)dc / (10.0 * (double)dr));
     }
 #endif
-    store_tile_bf16<BT, TM, TN>(p, acc, smem, C, m0, n0, wm0, wn0, t, lane, partial, sid, chunk);
+    store_tile_bf16<BT, TM, TN>(p, acc, smem, C, m0, n0, wm0, wn0, t, lane, partial, list_id, chunk);
 }
 
 // both operands read in 16-byte vectors, the 256 tile, K a multiple of 32 with k offsets affine inside aligned
@@ -895,14 +907,18 @@ template <int BT> __global__ void __launch_bounds__(256) splitk_fixup_bf16_kerne
     constexpr int ROWS = 16, VPR = BN / 2, RPP = 256 / VPR;  // column pairs per row, rows per pass
     const int tile_rel = blockIdx.x / (BM / ROWS);
     const int rblk = blockIdx.x % (BM / ROWS);
-    const int sid = p.dp_tiles + tile_rel;
+    int sid = p.dp_tiles + tile_rel, bz = 0;
+    if (p.flat_batch > 0) {  // the tile id counts through the batch entries (GemmParams::flat_batch)
+        bz = sid / (p.nbm * p.nbn);
+        sid -= bz * (p.nbm * p.nbn);
+    }
     const int width = p.group * p.nbn;
     const int first_m = (sid / width) * p.group;
     const int gsz = min(p.nbm - first_m, p.group);
     const int tm = first_m + (sid % width) % gsz;
     const int tn = (sid % width) / gsz;
     const float *slab0 = static_cast<const float *>(p.ws) + (int64_t)tile_rel * p.split * (BM * BN);
-    unsigned short *C = static_cast<unsigned short *>(p.C);
+    unsigned short *C = static_cast<unsigned short *>(p.C) + p.bat_c[bz];
     const float alpha = (float)p.alpha, beta = (float)p.beta;
     const int cv = threadIdx.x % VPR;
     const int64_t n = (int64_t)tn * BN + 2 * cv;
@@ -981,11 +997,12 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     q.nbn = sch.nbn;
     q.dp_tiles = sch.dp_tiles;
     q.split = sch.split;
+    q.flat_batch = sch.flat_batch;
     q.ws = ws;
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
     if (sch.nbm != (int)((p.M + BT - 1) / BT) || sch.nbn != (int)((p.N + BT - 1) / BT)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_bf16_kernel<LA, LB, BT>), dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1),
+    hipLaunchKernelGGL((gemm_bf16_kernel<LA, LB, BT>), dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), sch.flat_batch > 0 ? 1u : (unsigned)p.batch, 1),
                        dim3(2 * BT), 0, stream, q);
     if (sch.tail_tiles > 0)
         hipLaunchKernelGGL(splitk_fixup_bf16_kernel<BT>, dim3((unsigned)(sch.tail_tiles * (BT / 16))), dim3(256), 0, stream, q);
@@ -1003,11 +1020,12 @@ template <int LA, int LB, int KG> hipError_t launch_ring(const GemmParams &p, co
     q.nbn = sch.nbn;
     q.dp_tiles = sch.dp_tiles;
     q.split = sch.split;
+    q.flat_batch = sch.flat_batch;
     q.ws = ws;
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
     if (sch.nbm != (int)((p.M + BT - 1) / BT) || sch.nbn != (int)((p.N + BT - 1) / BT)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_bf16_ring_kernel<LA, LB, KG>), dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), (unsigned)p.batch, 1), dim3(2 * BT),
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<LA, LB, KG>), dim3((unsigned)(sch.dp_tiles + sch.tail_tiles * sch.split), sch.flat_batch > 0 ? 1u : (unsigned)p.batch, 1), dim3(2 * BT),
                        0, stream, q);
     if (sch.tail_tiles > 0)
         hipLaunchKernelGGL(splitk_fixup_bf16_kernel<BT>, dim3((unsigned)(sch.tail_tiles * (BT / 16))), dim3(256), 0, stream, q);
@@ -1026,8 +1044,15 @@ hipError_t schedule_gemm_bf16(int la, int lb, int bm, const GemmParams &p, GemmS
     GemmSchedule s;
     s.nbm = (int)((p.M + bt - 1) / bt);
     s.nbn = (int)((p.N + bt - 1) / bt);
-    const int64_t tiles = (int64_t)s.nbm * s.nbn;
+    int64_t tiles = (int64_t)s.nbm * s.nbn;
     if (tiles > 0x7FFFFFFF) return hipErrorInvalidValue;
+    // a batched launch: one list of tiles over all entries whenever its length fits a grid, cut like a single
+    // product's (CTC_TC_NO_FLAT_BATCH: A/B runs)
+    static const bool no_flat = getenv("CTC_TC_NO_FLAT_BATCH") != nullptr;
+    if (p.batch > 1 && !no_flat && tiles * p.batch <= 0x3FFFFF) {
+        s.flat_batch = p.batch;
+        tiles *= p.batch;
+    }
     s.dp_tiles = (int)tiles;
     s.split = 1;
     s.tail_tiles = 0;
@@ -1035,7 +1060,7 @@ hipError_t schedule_gemm_bf16(int la, int lb, int bm, const GemmParams &p, GemmS
     static const bool no_split = getenv("CTC_TC_NO_SPLITK") != nullptr;
     const int slots = bt == 256 ? bf16_slots<256>() : bf16_slots<128>();
     const int nk = (int)((p.K + BK - 1) / BK);
-    if (!no_split && slots > 0 && p.batch == 1) {
+    if (!no_split && slots > 0 && (p.batch == 1 || s.flat_batch > 0)) {
         const int tail = (int)(tiles % slots);
         if (tail > 0) {
             // f chunks per tail tile take ceil(tail * f / slots) rounds of (nk / f + overhead) K-tile

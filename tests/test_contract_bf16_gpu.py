@@ -67,6 +67,10 @@ CASES = [
     ("splitk_ragged_k_tail", "ak,bk->ab", dict(a=250, b=201, k=3064), ("k_vec", "k_vec")),
     ("splitk_scalar", "ak,kb->ab", dict(a=130, b=67, k=2221), ("scalar", "scalar")),
     ("splitk_permuted", "aeim,ebmj->abij", dict(a=8, b=8, i=16, j=16, e=48, m=64), None),
+    # batched launches: one list of tiles over the entries, cut along K like a single product's
+    ("batched_splitk", "zak,zkb->zab", dict(z=3, a=200, b=264, k=4096), ("k_vec", "outer_vec")),
+    ("batched_splitk_scalar", "zak,zbk->zab", dict(z=5, a=131, b=67, k=2221), ("scalar", "scalar")),
+    ("batched_splitk_middle_mode", "azk,kzb->azb", dict(z=4, a=136, b=200, k=3072), None),
 ]
 
 
@@ -98,6 +102,7 @@ BIG_TILE_CASES = [
     ("splitk_nt_k_tail", "ak,bk->ab", dict(a=300, b=264, k=3064), ("k_vec", "k_vec")),
     ("ccsd_24", "aeim,ebmj->abij", dict(a=24, b=24, i=24, j=24, e=16, m=24), None),
     ("batched", "zak,zkb->zab", dict(z=3, a=264, b=328, k=72), None),
+    ("batched_splitk", "zak,zkb->zab", dict(z=3, a=520, b=264, k=4096), None),
 ]
 
 

@@ -41,13 +41,23 @@ if os.environ.get("BATCHED_SMALL"):
              (20, 384, 384, 384), (3, 500, 500, 8000), (2, 1000, 1000, 1000), (12, 192, 192, 16384), (50, 64, 64, 4096), (4, 700, 900, 1100))
 if os.environ.get("PROBE_CASES"):  # "batch,m,n,k;batch,m,n,k;..."
     CASES = tuple(tuple(int(v) for v in c.split(",")) for c in os.environ["PROBE_CASES"].split(";"))
-for dt, tdt in (("f64", torch.float64), ("f32", torch.float32)):
+TYPES = (("f64", torch.float64), ("f32", torch.float32))
+if os.environ.get("BATCHED_BF16"):
+    TYPES = (("bf16", torch.bfloat16),)
+    PEAK["bf16"] = 2500.0
+    CASES = ((3, 3000, 3000, 3000), (5, 2048, 2048, 2048), (10, 1024, 1024, 1024), (12, 1024, 1024, 4096), (20, 768, 768, 2048), (6, 512, 640, 8192),
+             (33, 512, 512, 512), (3, 1024, 1024, 16384), (4, 2048, 2048, 2048), (64, 512, 512, 512), (7, 1536, 1536, 4096), (2, 4096, 4096, 4096), (50, 256, 256, 4096))
+for dt, tdt in TYPES:
     for z, m, n, k in CASES:
         A = torch.empty(z * m * k, dtype=tdt, device=dev)
         B = torch.empty(z * k * n, dtype=tdt, device=dev)
         C = torch.empty(z * m * n, dtype=tdt, device=dev)
-        ctc_amd.fill(A, 1)
-        ctc_amd.fill(B, 2)
+        if dt == "bf16":
+            A.copy_(torch.rand(A.numel(), dtype=torch.float32, device=dev) - 0.5)
+            B.copy_(torch.rand(B.numel(), dtype=torch.float32, device=dev) - 0.5)
+        else:
+            ctc_amd.fill(A, 1)
+            ctc_amd.fill(B, 2)
         plan = ctc_amd.Plan("zak,zkb->zab", dict(z=z, a=m, b=n, k=k), dt) if z > 1 else ctc_amd.Plan("ak,kb->ab", dict(a=m, b=n, k=k), dt)
         plan.prepare()
         ms = timed(lambda: plan.execute(A, B, C))
