@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(const GemmParams p)
             const int item = bid;
             bid += gridDim.x;
             if (item < p.dp_tiles) {
-                sid = xcd_run(item, p.dp_tiles);
+                sid = p.plain_order ? item : xcd_run(item, p.dp_tiles);
             } else if (p.sk_units > 0) {
                 sk_unit = xcd_run(item - p.dp_tiles, p.sk_units);
                 sk_it = sk_unit_start(sk_unit / p.sk_group, sk_total, sk_runs, nk_total);
@@ -727,6 +727,7 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     q.sk_units = sch.sk_units;
     q.sk_group = sch.sk_group > 0 ? sch.sk_group : 1;
     q.flat_batch = sch.flat_batch;
+    q.plain_order = (sch.flat_batch > 0 && sch.nbm * sch.nbn == 1) ? 1 : 0;
     q.ws = ws;
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;

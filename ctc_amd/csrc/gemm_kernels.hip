@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_kernel(const GemmParams 
         if (bid < p.dp_tiles) {
             const int nblk = p.dp_tiles;
             const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-            sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+            sid = p.plain_order ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         } else {
             const int item = bid - p.dp_tiles;
             sid = p.dp_tiles + item / p.split;
@@ -568,6 +568,7 @@ hipError_t launch_one(const GemmParams &p, const GemmSchedule &sch, void *ws, hi
     q.dp_tiles = sch.dp_tiles;
     q.split = sch.split;
     q.flat_batch = sch.flat_batch;
+    q.plain_order = (sch.flat_batch > 0 && sch.nbm * sch.nbn == 1) ? 1 : 0;
     q.ws = ws;
     if (q.group < 1) q.group = 1;
     if (sch.tail_tiles > 0 && ws == nullptr) return hipErrorInvalidValue;
