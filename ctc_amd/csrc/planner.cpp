@@ -142,7 +142,15 @@ void choose_tile(Plan &p)
         // through the copies against 49.5 on the small tile), so there the count alone decides as before.
         const bool vectors = p.layout_a != kLayoutScalar && p.layout_b != kLayoutScalar;
         const int64_t few_blocks = vectors ? 224 : (p.dtype == kF64 ? 256 : 0);
-        if (f > 1 && (big_blocks >= few_blocks || f >= 4)) big_chunks = big_blocks * f;
+        bool even = big_blocks >= few_blocks || f >= 4;
+        // ... unless some cut up to f ways loads the CUs evenly (169 tiles three ways are 1.98 chunks per CU: the
+        // headline contraction at extent 40, fp32 94 TFLOP/s on the large tile against 84 - 90 on the small one)
+        constexpr int64_t kAssumedCus = kAssumedSlots / 2;
+        for (int64_t c = 2; vectors && !even && c <= f; ++c) {
+            const int64_t chunks = big_blocks * c, per_cu = (chunks + kAssumedCus - 1) / kAssumedCus;
+            if (chunks >= kBigTileMinBlocks && 20 * chunks >= 17 * per_cu * kAssumedCus) even = true;  // 85 % of the busiest CU's load
+        }
+        if (f > 1 && even) big_chunks = big_blocks * f;
     }
     if (p.M >= 96 && p.N >= 96 && (big_blocks >= kBigTileMinBlocks || big_chunks >= kBigTileMinBlocks)) {
         t.bm = 128; t.bn = 128;
