@@ -58,27 +58,38 @@ namespace {
 
 // Many small products under a batch mode (M, N <= 32): the tiled kernels would multiply mostly padding (a 64 x 64
 // tile per 16 x 16 product: 1.9 TFLOP/s for 100,000 of them); the grouped kernel gives every product a wave of
-// its own (4.8).  It reads row-major operands with leading dimensions, so the plan's tables must say exactly
-// that: A(m, k) at m lda + k, B(k, n) at k ldb + n, C(m, n) at m ldc + n.  Measured against the tiled kernel
-// (tools/small_batched_probe.py): fp64 wins up to 32 x 32 (x 1.3 - 4.5), loses from 40 x 40 on; fp32 ties at 32^3.
+// its own (4.8).  It reads operands with one unit stride and one leading dimension each, so the plan's tables must
+// say exactly that: A(m, k) at m lda + k or at k lda + m, B(k, n) at k ldb + n or at n ldb + k, C(m, n) at
+// m ldc + n.  Measured against the tiled kernel (tools/small_batched_probe.py): fp64 wins up to 32 x 32
+// (x 1.3 - 4.5), loses from 40 x 40 on; fp32 ties at 32^3.
 std::atomic<int> g_small_batched{1};  // 0: never (A/B runs)
 std::atomic<int64_t> g_launches_grouped{0};
-bool small_batched(const ctc::Plan &p, int64_t &lda, int64_t &ldb, int64_t &ldc)
+
+// offsets a[i] + b[j] of an extent-na by extent-nb operand: unit stride along i and one leading dimension along j
+// (ld >= na)?  An extent of one fits any stride.
+bool unit_then_ld(const std::vector<int64_t> &a, int64_t na, const std::vector<int64_t> &b, int64_t nb, int64_t &ld)
+{
+    ld = nb > 1 ? b[1] : na;
+    if (ld < na || ld > 0x7FFFFFFF) return false;
+    for (int64_t i = 0; i < na; ++i)
+        if (a[(size_t)i] != i) return false;
+    for (int64_t j = 0; j < nb; ++j)
+        if (b[(size_t)j] != j * ld) return false;
+    return true;
+}
+
+bool small_batched(const ctc::Plan &p, int64_t &lda, int64_t &ldb, int64_t &ldc, bool &a_outer, bool &b_kmajor)
 {
     if (p.kernel != ctc::kKernelGemm || (p.dtype != ctc::kF64 && p.dtype != ctc::kF32) || p.batch < 512) return false;
     if (p.M < 1 || p.N < 1 || p.K < 1 || p.M > 32 || p.N > 32 || p.K > 64) return false;
     if (p.dtype == ctc::kF32 && p.M * p.N > 768 && p.K > 16) return false;
-    lda = p.M > 1 ? p.row_a[1] : p.K;
-    ldb = p.K > 1 ? p.k_b[1] : p.N;
-    ldc = p.M > 1 ? p.row_c[1] : p.N;
-    if (lda < p.K || ldb < p.N || ldc < p.N || lda > 0x7FFFFFFF || ldb > 0x7FFFFFFF || ldc > 0x7FFFFFFF) return false;
-    for (int64_t m = 0; m < p.M; ++m)
-        if (p.row_a[(size_t)m] != m * lda || p.row_c[(size_t)m] != m * ldc) return false;
-    for (int64_t k = 0; k < p.K; ++k)
-        if (p.k_a[(size_t)k] != k || p.k_b[(size_t)k] != k * ldb) return false;
-    for (int64_t n = 0; n < p.N; ++n)
-        if (p.col_b[(size_t)n] != n || p.col_c[(size_t)n] != n) return false;
-    return true;
+    if (unit_then_ld(p.k_a, p.K, p.row_a, p.M, lda)) a_outer = false;       // [m][k]
+    else if (unit_then_ld(p.row_a, p.M, p.k_a, p.K, lda)) a_outer = true;   // [k][m]
+    else return false;
+    if (unit_then_ld(p.col_b, p.N, p.k_b, p.K, ldb)) b_kmajor = false;      // [k][n]
+    else if (unit_then_ld(p.k_b, p.K, p.col_b, p.N, ldb)) b_kmajor = true;  // [n][k]
+    else return false;
+    return unit_then_ld(p.col_c, p.N, p.row_c, p.M, ldc);
 }
 
 int upload_tables(ctc_tc_plan *pl, int device, DeviceTables &out, bool no_alloc = false)
@@ -136,7 +147,7 @@ int upload_tables(ctc_tc_plan *pl, int device, DeviceTables &out, bool no_alloc 
     t.bat_c = t.base + start[8];
     for (int i = 0; i < 6; ++i) t.sk[i] = t.base + start[9 + i];
     int64_t lda = 0, ldb = 0, ldc = 0;
-    if (small_batched(p, lda, ldb, ldc)) {
+    if (small_batched(p, lda, ldb, ldc, t.small_a_outer, t.small_b_kmajor)) {
         std::vector<ctc::SmallGemm> desc((size_t)p.batch);
         for (int64_t z = 0; z < p.batch; ++z)
             desc[(size_t)z] = ctc::SmallGemm{(int32_t)p.M, (int32_t)p.N, (int32_t)p.K, (int32_t)lda, (int32_t)ldb, (int32_t)ldc,
@@ -363,7 +374,8 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
 
     if (t.small && g_small_batched.load() != 0 && p.batch <= 0x7FFFFFFF) {
         // one wave per product, all of the batch in one launch (GEMM operands: A and B exchanged when the plan says so)
-        hipError_t e = ctc::launch_grouped(p.dtype, t.small, (int)p.batch, p.swapped ? B : A, p.swapped ? A : B, C, alpha, beta, stream);
+        hipError_t e = ctc::launch_grouped(p.dtype, t.small, (int)p.batch, p.swapped ? B : A, p.swapped ? A : B, C, alpha, beta, stream,
+                                           t.small_a_outer, t.small_b_kmajor);
         if (e != hipSuccess) return fail_hip(e, "grouped kernel launch");
         g_launches_grouped.fetch_add(1);
         return CTC_TC_OK;

@@ -26,6 +26,7 @@ struct DeviceTables {
     const int64_t *sk[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // bx cx by cy bo co
     // a batch of small row-major products (see small_batched in api.cpp): one descriptor per batch entry
     ctc::SmallGemm *small = nullptr;
+    bool small_a_outer = false, small_b_kmajor = false;  // how the descriptors' operands are stored (ctc::launch_grouped)
     // workspace of this plan on this device (split-K partial sums, or the three packed tensors of the
     // explicit-transpose path): grows on demand; executions on different streams are ordered through
     // ws_done so that they never share it concurrently

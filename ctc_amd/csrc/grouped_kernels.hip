@@ -24,7 +24,9 @@ template <> struct Mf<float> {
     static __device__ __forceinline__ int acc_row(int lane, int j) { return (lane >> 4) * 4 + j; }
 };
 
-template <typename T>
+// AT: A is stored [k][m] (A(m, k) at k lda + m) instead of [m][k]; BT: B is stored [n][k] (B(k, n) at n ldb + k)
+// instead of [k][n].  The public entry point takes the plain forms; batched plans of small products take all four.
+template <typename T, bool AT, bool BT>
 __global__ void __launch_bounds__(256) grouped_kernel(const SmallGemm *__restrict__ problems, int count, const T *A,
                                                       const T *B, T *C, T alpha, T beta)
 {
@@ -49,15 +51,18 @@ __global__ void __launch_bounds__(256) grouped_kernel(const SmallGemm *__restric
                 const int r0 = m0 + fr, r1 = m0 + 16 + fr;
                 const int c0 = n0 + fr, c1 = n0 + 16 + fr;
                 const bool r0ok = r0 < g.m, r1ok = r1 < g.m, c0ok = c0 < g.n, c1ok = c1 < g.n;
-                const T *a0 = a + (int64_t)(r0ok ? r0 : 0) * g.lda;
-                const T *a1 = a + (int64_t)(r1ok ? r1 : 0) * g.lda;
+                // strides of a row / of k in A, of k / of a column in B
+                const int64_t a_row = AT ? 1 : g.lda, a_k = AT ? g.lda : 1, b_k = BT ? 1 : g.ldb, b_col = BT ? g.ldb : 1;
+                const T *a0 = a + (int64_t)(r0ok ? r0 : 0) * a_row;
+                const T *a1 = a + (int64_t)(r1ok ? r1 : 0) * a_row;
+                const T *b0 = b + (int64_t)(c0ok ? c0 : 0) * b_col;
+                const T *b1 = b + (int64_t)(c1ok ? c1 : 0) * b_col;
                 for (int k0 = 0; k0 < g.k; k0 += 4) {
                     const int k = k0 + fk;
                     const bool kok = k < g.k;
                     const int kc = kok ? k : 0;
-                    const T *brow = b + (int64_t)kc * g.ldb;
-                    T fa0 = a0[kc], fa1 = a1[kc];
-                    T fb0 = brow[c0ok ? c0 : 0], fb1 = brow[c1ok ? c1 : 0];
+                    T fa0 = a0[kc * a_k], fa1 = a1[kc * a_k];
+                    T fb0 = b0[kc * b_k], fb1 = b1[kc * b_k];
                     // zero what lies outside the problem: k tail in both operands, rows/columns past the edge
                     if (!(kok && r0ok)) fa0 = 0;
                     if (!(kok && r1ok)) fa1 = 0;
@@ -91,20 +96,34 @@ __global__ void __launch_bounds__(256) grouped_kernel(const SmallGemm *__restric
 
 }  // namespace
 
+namespace {
+template <typename T, bool AT, bool BT>
+void launch_one(const SmallGemm *problems, int count, const void *A, const void *B, void *C, double alpha, double beta, int blocks,
+                hipStream_t stream)
+{
+    hipLaunchKernelGGL((grouped_kernel<T, AT, BT>), dim3(blocks), dim3(256), 0, stream, problems, count, static_cast<const T *>(A),
+                       static_cast<const T *>(B), static_cast<T *>(C), (T)alpha, (T)beta);
+}
+template <typename T>
+void launch_forms(bool at, bool bt, const SmallGemm *problems, int count, const void *A, const void *B, void *C, double alpha,
+                  double beta, int blocks, hipStream_t stream)
+{
+    if (!at && !bt) launch_one<T, false, false>(problems, count, A, B, C, alpha, beta, blocks, stream);
+    else if (!at) launch_one<T, false, true>(problems, count, A, B, C, alpha, beta, blocks, stream);
+    else if (!bt) launch_one<T, true, false>(problems, count, A, B, C, alpha, beta, blocks, stream);
+    else launch_one<T, true, true>(problems, count, A, B, C, alpha, beta, blocks, stream);
+}
+}  // namespace
+
 hipError_t launch_grouped(int dtype, const SmallGemm *problems, int count, const void *A, const void *B, void *C,
-                          double alpha, double beta, hipStream_t stream)
+                          double alpha, double beta, hipStream_t stream, bool a_outer, bool b_kmajor)
 {
     if (count <= 0) return hipSuccess;
     int blocks = (count + 3) / 4;  // four waves per workgroup, one problem per wave and pass
     if (blocks > 256 * 8) blocks = 256 * 8;
-    if (dtype == 0)
-        hipLaunchKernelGGL(grouped_kernel<double>, dim3(blocks), dim3(256), 0, stream, problems, count,
-                           static_cast<const double *>(A), static_cast<const double *>(B), static_cast<double *>(C), alpha, beta);
-    else if (dtype == 1)
-        hipLaunchKernelGGL(grouped_kernel<float>, dim3(blocks), dim3(256), 0, stream, problems, count,
-                           static_cast<const float *>(A), static_cast<const float *>(B), static_cast<float *>(C), (float)alpha, (float)beta);
-    else
-        return hipErrorInvalidValue;
+    if (dtype == 0) launch_forms<double>(a_outer, b_kmajor, problems, count, A, B, C, alpha, beta, blocks, stream);
+    else if (dtype == 1) launch_forms<float>(a_outer, b_kmajor, problems, count, A, B, C, alpha, beta, blocks, stream);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -146,8 +146,9 @@ struct SmallGemm {
     int32_t lda, ldb, ldc;
     int64_t off_a, off_b, off_c;
 };
+// a_outer: every A is stored [k][m] (lda: stride of k); b_kmajor: every B is stored [n][k] (ldb: stride of a column)
 hipError_t launch_grouped(int dtype, const SmallGemm *problems_device, int count, const void *A, const void *B,
-                          void *C, double alpha, double beta, hipStream_t stream);
+                          void *C, double alpha, double beta, hipStream_t stream, bool a_outer = false, bool b_kmajor = false);
 
 // FASTR scoring: one work item = one consensus x up to fastr_reads_per_block() reads.
 struct FastrWork {

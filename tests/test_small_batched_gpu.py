@@ -1,6 +1,6 @@
 """Batches of small products (zab = zak,zkb with M, N <= 32): the plan runs on the grouped kernel, one wave per
 product, instead of the tiled kernels.  Against the CPU oracle, with alpha / beta, roles exchanged, and the shapes
-that must NOT take it (larger products, a K-major second operand, strided rows are fine: leading dimensions)."""
+that must NOT take it (larger products, a C stored along the batch mode; strided rows are fine: leading dimensions)."""
 import numpy as np
 import pytest
 import torch
@@ -46,11 +46,16 @@ def test_batches_of_small_products_take_the_grouped_kernel(cuda, oracle, dtype):
     # C's unit-stride mode belongs to the first operand: the roles are exchanged and the tables still describe
     # row-major products
     _run(cuda, oracle, "zkb,zak->zab", dict(z=1000, a=16, b=24, k=8), dtype, True)
+    # the other storage orders of the operands: A as [k][m], B as [n][k], both; a batch mode in the middle
+    _run(cuda, oracle, "zak,zbk->zab", dict(z=900, a=16, b=16, k=16), dtype, True, alpha=2.0, beta=0.5)
+    _run(cuda, oracle, "zka,zkb->zab", dict(z=900, a=12, b=20, k=28), dtype, True)
+    _run(cuda, oracle, "zka,zbk->zab", dict(z=800, a=7, b=9, k=5), dtype, True, beta=-1.0)
+    _run(cuda, oracle, "azk,kzb->azb", dict(z=700, a=16, b=12, k=24), dtype, True)
 
 
 def test_shapes_that_keep_the_tiled_kernels(cuda, oracle):
     _run(cuda, oracle, "zak,zkb->zab", dict(z=600, a=40, b=40, k=16), "f64", False)       # larger than 32 x 32
-    _run(cuda, oracle, "zak,zbk->zab", dict(z=600, a=16, b=16, k=16), "f64", False)       # second operand K-major
+    _run(cuda, oracle, "zak,zkb->abz", dict(z=600, a=16, b=16, k=16), "f64", False)       # C stored along the batch mode
     _run(cuda, oracle, "zak,zkb->zab", dict(z=100, a=16, b=16, k=16), "f64", False)       # a small batch
     _run(cuda, oracle, "zak,zkb->zab", dict(z=600, a=32, b=32, k=32), "f32", False)       # fp32 ties there
     ctc_amd.set_option("small_batched", 0)
