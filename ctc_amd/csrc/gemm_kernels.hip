@@ -445,7 +445,7 @@ inline int device_cus()
 // 256 / 512 / 768 / 1024 tiles) although 1024 of its workgroups are resident at once (tools/tail_cost_probe.py).
 // d: while a CU holds a single workgroup of the small tile, that workgroup is latency-bound and runs at about two
 // thirds of the CU's rate (the first step above is 1.5 - 1.85 times the later ones); it stays with the longest
-// items of a launch.  The large tile shows no such term.
+// items of a launch.  The large tile shows less of it (0.25 fp64, 0.5 fp32).
 // Three schedules, costs in K-tile times (nk per whole tile, nk / f + overhead per chunk, where the overhead -
 // prologue, raw accumulators to the workspace, the chunk's share of the fix-up pass - is `ovh` K-tiles, and a cut
 // at all - the second launch - `pen` more), tiles = w * cus + tail:
@@ -541,12 +541,18 @@ hipError_t schedule_one(const GemmParams &p, GemmSchedule *out)
     // K = 400 ... 800 lose by what 30 make up; a quarter of that in K-tiles of the large tile)
     constexpr int kChunkOverhead = BM <= 64 ? 6 : kMinChunkTiles;
     constexpr int kCutPenalty = BM <= 64 ? (sizeof(T) == 4 ? 32 : 10) : (sizeof(T) == 4 ? 8 : 3);
-    constexpr double kLoneWorkgroup = BM <= 64 ? (sizeof(T) == 4 ? 0.75 : 0.5) : 0.0;
+    // (large tile, operands through registers: 256 tiles of fp64 K = 4097 gain 3.5 % cut in two, 192 of fp32 17 % cut in five)
+    constexpr double kLoneWorkgroup = BM <= 64 ? (sizeof(T) == 4 ? 0.75 : 0.5) : (sizeof(T) == 4 ? 0.5 : 0.25);
     static const bool by_slots = getenv("CTC_TC_SPLIT_BY_SLOTS") != nullptr;
     const int cus = device_cus();
     if (!no_split && slots > 0 && cus > 0 && (p.batch == 1 || s.flat_batch > 0)) {
-        const SplitChoice c = by_slots ? best_split_by_slots(tiles, slots, nk)
-                                       : best_split(tiles, cus, nk, kChunkOverhead, kCutPenalty, kLoneWorkgroup);
+        // The large tile with more tiles than slots keeps the rounds of slots: its late workgroups do not land
+        // one per CU (fp64, element loads of A, K = 4097: 640, 768 and 1024 tiles all take the time of two full
+        // rounds; 768 tiles cut by rounds of slots run at 67.2 TFLOP/s, left whole as the balance per CU
+        // suggests at 52.4), and this kernel has no form in which workgroups walk their items.
+        const bool slots_rule = by_slots || (BM > 64 && tiles > slots);
+        const SplitChoice c = slots_rule ? best_split_by_slots(tiles, slots, nk)
+                                         : best_split(tiles, cus, nk, kChunkOverhead, kCutPenalty, kLoneWorkgroup);
         if (c.f >= 2 && c.cut > 0) {
             s.tail_tiles = (int)c.cut;
             s.dp_tiles = (int)(tiles - c.cut);

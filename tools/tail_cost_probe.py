@@ -44,6 +44,10 @@ if os.environ.get("TAIL_PROBE_SMALL"):
     EDGE = 64
     GRIDS = ((8, 8), (8, 16), (12, 16), (16, 16), (16, 20), (16, 24), (16, 32), (20, 32), (24, 32), (28, 32), (32, 32), (32, 36), (32, 40), (32, 48), (32, 64))
     KS = (576, 1024, 4096)
+if os.environ.get("TAIL_PROBE_ODDK"):
+    # an odd K: A by element loads, the register-staged kernel on the large tile
+    GRIDS = ((4, 16), (8, 16), (12, 16), (16, 16), (16, 20), (16, 24), (16, 32), (20, 32), (24, 32), (32, 32), (32, 40))
+    KS = (1025, 4097)
 if os.environ.get("TAIL_PROBE_BF16"):
     # the 128 x 128 bf16 tile (the planner takes it below 192 tiles of 256 x 256)
     GRIDS = ((8, 16), (8, 32), (12, 32), (14, 32), (16, 32), (18, 32), (20, 32), (22, 32))
