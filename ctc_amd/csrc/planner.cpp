@@ -144,7 +144,8 @@ void choose_tile(Plan &p)
         // through the copies against 49.5 on the small tile), so there the count alone decides as before.
         const bool vectors = p.layout_a != kLayoutScalar && p.layout_b != kLayoutScalar;
         const int64_t few_blocks = vectors ? 224 : (p.dtype == kF64 ? 256 : 0);
-        bool even = big_blocks >= few_blocks || f >= 4;
+        static const bool old_rule = getenv("CTC_TC_OLD_TILE_RULE") != nullptr;  // A/B runs: the count of chunks alone
+        bool even = old_rule || big_blocks >= few_blocks || f >= 4;
         // ... unless some cut up to f ways loads the CUs evenly (169 tiles three ways are 1.98 chunks per CU: the
         // headline contraction at extent 40, fp32 94 TFLOP/s on the large tile against 84 - 90 on the small one)
         constexpr int64_t kAssumedCus = kAssumedSlots / 2;
