@@ -455,7 +455,13 @@ std::string build_plan(const std::string &spec, int n_ext, const char *mode_name
         // CTC_TC_PAD_MIN_MN / CTC_TC_PAD_MIN_K: calibration knobs
         static const int64_t env_mn = getenv("CTC_TC_PAD_MIN_MN") ? atoll(getenv("CTC_TC_PAD_MIN_MN")) : 0;
         static const int64_t env_k = getenv("CTC_TC_PAD_MIN_K") ? atoll(getenv("CTC_TC_PAD_MIN_K")) : 0;
-        const int64_t min_mn = env_mn > 0 ? env_mn : (dtype == kF64 ? 2048 : 1024), min_k = env_k > 0 ? env_k : (dtype == kF64 ? 1024 : 512);
+        // fp32 with an operand that is read by elements ACROSS its rows (its unit-stride mode is a free one, of an odd
+        // extent): the copies pay from 512 x 512 on (979 x 2363 x 6616 `ka,kb`: 63 -> 99 TFLOP/s, `ak,kb` 81 -> 100;
+        // 515 x 5001 x 1025 `ka,kb` 35 -> 57; two operands read along K tie or lose there, fp64 ties)
+        const bool a_across = p.layout_a == kLayoutScalar && a_unit >= 0 && !a_unit_is_k;
+        const bool b_across = p.layout_b == kLayoutScalar && b_unit >= 0 && !b_unit_is_k;
+        const int64_t f32_mn = (dtype == kF32 && (a_across || b_across)) ? 512 : 1024;
+        const int64_t min_mn = env_mn > 0 ? env_mn : (dtype == kF64 ? 2048 : f32_mn), min_k = env_k > 0 ? env_k : (dtype == kF64 ? 1024 : 512);
         p.k_padded = (p.K + unit - 1) / unit * unit;
         // bf16 also when the k tables are affine in groups shorter than 16 only (the fastest contracted mode's
         // extent is no multiple of 16): the ring kernel (K-tiles of 32, one table entry per tile or half tile) cannot
