@@ -160,7 +160,9 @@ void choose_tile(Plan &p)
     // 40.5 -> 46.0, fp32 57.0 -> 76.4; at 12 - 14 % more the large tile still leads by up to 5 %).
     auto padded = [&](int64_t edge) { return (double)((p.M + edge - 1) / edge * edge) * (double)((p.N + edge - 1) / edge * edge); };
     static const bool mind_padding = getenv("CTC_TC_OLD_TILE_RULE") == nullptr;
-    const bool too_much_padding = mind_padding && padded(128) >= 1.15 * padded(64);
+    // (under a K below 2048 from 10 % more on: 16 x 858 x 546 x 89 22.8 -> 30.3, 64 x 580 x 404 x 217 34.7 -> 40.9, fp32
+    // 32 x 400 x 1120 x 288 74.1 -> 84.9)
+    const bool too_much_padding = mind_padding && padded(128) >= (p.K >= 2048 ? 1.15 : 1.10) * padded(64);
     if (p.M >= 96 && p.N >= 96 && !too_much_padding && (big_blocks >= kBigTileMinBlocks || big_chunks >= kBigTileMinBlocks)) {
         t.bm = 128; t.bn = 128;
     } else {

@@ -404,7 +404,7 @@ BATCHED_TAIL_CASES = [
     ("fewer_tiles_than_slots", "zak,zkb->zab", dict(z=3, a=640, b=512, k=4096), "f64"),          # 60 tiles
     ("one_round_and_a_bit", "zak,zbk->zab", dict(z=5, a=1408, b=1300, k=1024), "f64"),            # 605 tiles
     ("two_rounds_and_a_bit", "zka,zkb->zab", dict(z=13, a=1000, b=1400, k=1536), "f64"),          # 1144 tiles
-    ("batch_mode_in_the_middle", "azk,kzb->azb", dict(z=3, a=1200, b=900, k=1280), "f64"),
+    ("batch_mode_in_the_middle", "azk,kzb->azb", dict(z=3, a=1280, b=1024, k=1280), "f64"),
     ("two_batch_modes", "yzak,yzkb->yzab", dict(y=2, z=3, a=1000, b=1100, k=384), "f64"),
     ("ragged_k_tiles", "zaef,zfeb->zab", dict(z=4, a=1280, b=1280, e=20, f=14), "f64"),
     ("f32_one_round_and_a_bit", "zak,zkb->zab", dict(z=5, a=1408, b=1300, k=2048), "f32"),
