@@ -57,21 +57,28 @@ __global__ void __launch_bounds__(256) grouped_kernel(const SmallGemm *__restric
                 const T *a1 = a + (int64_t)(r1ok ? r1 : 0) * a_row;
                 const T *b0 = b + (int64_t)(c0ok ? c0 : 0) * b_col;
                 const T *b1 = b + (int64_t)(c1ok ? c1 : 0) * b_col;
+                // a block with at most 16 rows (columns) inside the problem needs one row (column) of MFMAs only:
+                // uniform per problem, so a batch of 8 x 8 or 16 x 16 products issues a quarter of the MFMAs and half
+                // of the loads
+                const bool two_m = g.m - m0 > 16, two_n = g.n - n0 > 16;
                 for (int k0 = 0; k0 < g.k; k0 += 4) {
                     const int k = k0 + fk;
                     const bool kok = k < g.k;
                     const int kc = kok ? k : 0;
-                    T fa0 = a0[kc * a_k], fa1 = a1[kc * a_k];
-                    T fb0 = b0[kc * b_k], fb1 = b1[kc * b_k];
+                    T fa0 = a0[kc * a_k], fb0 = b0[kc * b_k], fa1 = 0, fb1 = 0;
+                    if (two_m) fa1 = a1[kc * a_k];
+                    if (two_n) fb1 = b1[kc * b_k];
                     // zero what lies outside the problem: k tail in both operands, rows/columns past the edge
                     if (!(kok && r0ok)) fa0 = 0;
                     if (!(kok && r1ok)) fa1 = 0;
                     if (!(kok && c0ok)) fb0 = 0;
                     if (!(kok && c1ok)) fb1 = 0;
                     acc[0][0] = Mf<T>::mfma(fa0, fb0, acc[0][0]);
-                    acc[0][1] = Mf<T>::mfma(fa0, fb1, acc[0][1]);
-                    acc[1][0] = Mf<T>::mfma(fa1, fb0, acc[1][0]);
-                    acc[1][1] = Mf<T>::mfma(fa1, fb1, acc[1][1]);
+                    if (two_n) acc[0][1] = Mf<T>::mfma(fa0, fb1, acc[0][1]);
+                    if (two_m) {
+                        acc[1][0] = Mf<T>::mfma(fa1, fb0, acc[1][0]);
+                        if (two_n) acc[1][1] = Mf<T>::mfma(fa1, fb1, acc[1][1]);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
