@@ -63,6 +63,7 @@ namespace {
 // m ldc + n.  Measured against the tiled kernel (tools/small_batched_probe.py): fp64 wins up to 32 x 32
 // (x 1.3 - 4.5), loses from 40 x 40 on; fp32 ties at 32^3.
 std::atomic<int> g_small_batched{1};  // 0: never (A/B runs)
+std::atomic<int> g_small_equal{getenv("CTC_TC_NO_SMALL_EQUAL") ? 0 : 1};  // four products of at most 16 x 16 per wave
 std::atomic<int64_t> g_launches_grouped{0};
 
 // offsets a[i] + b[j] of an extent-na by extent-nb operand: unit stride along i and one leading dimension along j
@@ -375,7 +376,9 @@ int launch_plan(ctc_tc_plan *pl, double alpha, const void *A, const void *B, dou
     if (t.small && g_small_batched.load() != 0 && p.batch <= 0x7FFFFFFF) {
         // one wave per product, all of the batch in one launch (GEMM operands: A and B exchanged when the plan says so)
         hipError_t e = ctc::launch_grouped(p.dtype, t.small, (int)p.batch, p.swapped ? B : A, p.swapped ? A : B, C, alpha, beta, stream,
-                                           t.small_a_outer, t.small_b_kmajor);
+                                           t.small_a_outer, t.small_b_kmajor,
+                                           // (four per wave pays where the fixed work per wave dominates: under K = 64 it ties or loses)
+                                           p.M <= 16 && p.N <= 16 && p.K <= 32 && g_small_equal.load() != 0);
         if (e != hipSuccess) return fail_hip(e, "grouped kernel launch");
         g_launches_grouped.fetch_add(1);
         return CTC_TC_OK;

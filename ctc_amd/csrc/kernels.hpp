@@ -148,7 +148,8 @@ struct SmallGemm {
 };
 // a_outer: every A is stored [k][m] (lda: stride of k); b_kmajor: every B is stored [n][k] (ldb: stride of a column)
 hipError_t launch_grouped(int dtype, const SmallGemm *problems_device, int count, const void *A, const void *B,
-                          void *C, double alpha, double beta, hipStream_t stream, bool a_outer = false, bool b_kmajor = false);
+                          void *C, double alpha, double beta, hipStream_t stream, bool a_outer = false, bool b_kmajor = false,
+                          bool small_equal = false);  // small_equal: every problem has the first one's m, n <= 16, k and leading dimensions
 
 // FASTR scoring: one work item = one consensus x up to fastr_reads_per_block() reads.
 struct FastrWork {

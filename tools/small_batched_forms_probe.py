@@ -30,7 +30,7 @@ def timed(fn, iters=6, seconds=0.1):
 
 dev = torch.device("cuda:0")
 for dt, tdt in (("f64", torch.float64), ("f32", torch.float32)):
-    for z, m, n, k in ((100000, 16, 16, 16), (50000, 24, 24, 24), (30000, 32, 32, 32), (50000, 12, 20, 28), (50000, 16, 16, 64)):
+    for z, m, n, k in ((100000, 16, 16, 16), (100000, 8, 8, 8), (100000, 12, 16, 32), (200000, 4, 4, 4), (50000, 24, 24, 24), (30000, 32, 32, 32), (50000, 12, 20, 28), (50000, 16, 16, 64)):
         for spec in ("zak,zkb->zab", "zak,zbk->zab", "zka,zkb->zab", "zka,zbk->zab"):
             A = torch.empty(z * m * k, dtype=tdt, device=dev)
             B = torch.empty(z * k * n, dtype=tdt, device=dev)
