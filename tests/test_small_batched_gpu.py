@@ -37,6 +37,17 @@ def _run(cuda, oracle, spec, ext, dtype, expect_grouped, alpha=1.0, beta=0.0, st
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("z", [513, 514, 515, 1023])
+def test_four_small_products_per_wave_with_a_ragged_count(cuda, oracle, dtype, z):
+    """Products of at most 16 x 16 under K <= 32 share a wave four at a time: batch counts that are no multiple of
+    four (the last wave holds one to three), odd sizes, alpha / beta, every operand order."""
+    _run(cuda, oracle, "zak,zkb->zab", dict(z=z, a=8, b=8, k=8), dtype, True, alpha=1.5, beta=-0.5)
+    _run(cuda, oracle, "zka,zbk->zab", dict(z=z, a=5, b=16, k=31), dtype, True)
+    _run(cuda, oracle, "zak,zbk->zab", dict(z=z, a=16, b=3, k=1), dtype, True, beta=2.0)
+    _run(cuda, oracle, "zka,zkb->zab", dict(z=z, a=1, b=1, k=32), dtype, True)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_batches_of_small_products_take_the_grouped_kernel(cuda, oracle, dtype):
     _run(cuda, oracle, "zak,zkb->zab", dict(z=3000, a=16, b=16, k=16), dtype, True)
     _run(cuda, oracle, "zak,zkb->zab", dict(z=2000, a=12, b=20, k=28), dtype, True, alpha=-0.5, beta=1.25)
