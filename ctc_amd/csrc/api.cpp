@@ -82,7 +82,12 @@ bool unit_then_ld(const std::vector<int64_t> &a, int64_t na, const std::vector<i
 bool small_batched(const ctc::Plan &p, int64_t &lda, int64_t &ldb, int64_t &ldc, bool &a_outer, bool &b_kmajor)
 {
     if (p.kernel != ctc::kKernelGemm || (p.dtype != ctc::kF64 && p.dtype != ctc::kF32) || p.batch < 512) return false;
-    if (p.M < 1 || p.N < 1 || p.K < 1 || p.M > 32 || p.N > 32 || p.K > 64) return false;
+    if (p.M < 1 || p.N < 1 || p.K < 1 || p.M > 32 || p.N > 32) return false;
+    // how long a K: products of at most 16 x 16 gain at every K measured (50,000 x 16 x 16 x 128: x 2.2, 10,000 x 16 x 16 x
+    // 1024: x 1.9, fp32 x 1.5 - 1.6), 24 x 24 fp64 still x 1.4 at K = 96; 32 x 32 ties from K = 128 on and fp32 loses there
+    const int64_t small = p.M > p.N ? p.M : p.N;
+    const int64_t max_k = small <= 16 ? 4096 : (small <= 24 && p.dtype == ctc::kF64 ? 128 : 64);
+    if (p.K > max_k) return false;
     if (p.dtype == ctc::kF32 && p.M * p.N > 768 && p.K > 16) return false;
     if (unit_then_ld(p.k_a, p.K, p.row_a, p.M, lda)) a_outer = false;       // [m][k]
     else if (unit_then_ld(p.row_a, p.M, p.k_a, p.K, lda)) a_outer = true;   // [k][m]

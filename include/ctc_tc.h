@@ -160,7 +160,7 @@ const char *ctc_tc_last_error(void);
  *                   equal shares (stream-K); 1: never shares; 2: shares whenever the launch allows;
  *   "stream_k_group" consecutive tiles whose shares walk K together (1 .. 64); 0 (default): 16, or 8 where that
  *                   leaves less padding;
- *   "small_batched" 1 (default): a batch of at least 512 products with M, N <= 32 and K <= 64, operands with one unit stride each (fp32: not
+ *   "small_batched" 1 (default): a batch of at least 512 products with M, N <= 32 and K <= 64 (M, N <= 16: K <= 4096), operands with one unit stride each (fp32: not
  *                   32 x 32 under a K above 16) runs on the grouped kernel, one wave per product; 0: on the tiled kernels;
  *   "pad_transposes" 1 (default): a plan whose CTC_TC_Q_TILE reports transposes = 2 runs through the padded copies;
  *                   0: it runs the fused kernel with element loads (A/B runs).

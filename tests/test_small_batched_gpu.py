@@ -62,6 +62,10 @@ def test_batches_of_small_products_take_the_grouped_kernel(cuda, oracle, dtype):
     _run(cuda, oracle, "zka,zkb->zab", dict(z=900, a=12, b=20, k=28), dtype, True)
     _run(cuda, oracle, "zka,zbk->zab", dict(z=800, a=7, b=9, k=5), dtype, True, beta=-1.0)
     _run(cuda, oracle, "azk,kzb->azb", dict(z=700, a=16, b=12, k=24), dtype, True)
+    # small products under a longer K
+    _run(cuda, oracle, "zak,zkb->zab", dict(z=600, a=16, b=16, k=1000), dtype, True, alpha=0.5, beta=0.5)
+    _run(cuda, oracle, "zka,zbk->zab", dict(z=600, a=9, b=13, k=257), dtype, True)
+    _run(cuda, oracle, "zak,zkb->zab", dict(z=600, a=24, b=24, k=96), dtype, dtype == "f64")
 
 
 def test_shapes_that_keep_the_tiled_kernels(cuda, oracle):

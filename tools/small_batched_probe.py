@@ -31,8 +31,11 @@ def timed(fn, iters=6, seconds=0.1):
 
 dev = torch.device("cuda:0")
 for dt, tdt in (("f64", torch.float64), ("f32", torch.float32)):
-    for z, m, n, k in ((100000, 16, 16, 16), (100000, 8, 8, 8), (50000, 24, 24, 24), (30000, 32, 32, 32), (20000, 40, 40, 40), (10000, 48, 48, 48),
-                       (8000, 64, 64, 64), (50000, 16, 16, 64), (50000, 32, 32, 8), (50000, 12, 20, 28)):
+    CASES = ((100000, 16, 16, 16), (100000, 8, 8, 8), (50000, 24, 24, 24), (30000, 32, 32, 32), (20000, 40, 40, 40), (10000, 48, 48, 48),
+                       (8000, 64, 64, 64), (50000, 16, 16, 64), (50000, 32, 32, 8), (50000, 12, 20, 28))
+    if os.environ.get("SMALL_LONG_K"):  # beyond the K the plan route takes
+        CASES = ((50000, 16, 16, 128), (20000, 16, 16, 256), (20000, 32, 32, 128), (10000, 32, 32, 256), (50000, 8, 8, 128), (10000, 16, 16, 1024), (20000, 24, 24, 96))
+    for z, m, n, k in CASES:
         A = torch.empty(z * m * k, dtype=tdt, device=dev)
         B = torch.empty(z * k * n, dtype=tdt, device=dev)
         C1 = torch.empty(z * m * n, dtype=tdt, device=dev)
